@@ -1,0 +1,473 @@
+/*
+ * pose_oracle.c -- CPU restatement of the reference's RANSAC pose-hypothesis path.
+ * TEST INFRASTRUCTURE ONLY (see pose_oracle.h).  Plain C99, no dependencies beyond libm.
+ */
+#include "pose_oracle.h"
+#include "p4pf_template.h"
+#include <complex.h>
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ===================================================================================== */
+/* complex helpers that spell out what libstdc++'s std::complex<double> does, so that     */
+/* signed zeros and branch cuts follow the reference binary (g++ on x86-64 Linux).        */
+/* ===================================================================================== */
+typedef struct { double re, im; } cd;
+static cd cd_make(double re, double im) { cd z = {re, im}; return z; }
+static cd cd_add(cd a, cd b) { return cd_make(a.re + b.re, a.im + b.im); }
+static cd cd_sub(cd a, cd b) { return cd_make(a.re - b.re, a.im - b.im); }
+static cd cd_neg(cd a) { return cd_make(-a.re, -a.im); }
+static cd cd_scale(cd a, double s) { return cd_make(a.re * s, a.im * s); }      /* complex*T, T*complex */
+static cd cd_divs(cd a, double s) { return cd_make(a.re / s, a.im / s); }       /* complex/T */
+static cd cd_adds(cd a, double s) { return cd_make(a.re + s, a.im); }           /* T+complex, complex+T */
+static cd cd_rsub(double s, cd a) { return cd_make(-a.re + s, -a.im); }         /* T-complex: r=-y; r+=x */
+static cd cd_div(cd a, cd b)                                                     /* complex/complex (__divdc3) */
+{
+    double complex q = CMPLX(a.re, a.im) / CMPLX(b.re, b.im);
+    return cd_make(creal(q), cimag(q));
+}
+static cd cd_sqrt(cd a) { double complex q = csqrt(CMPLX(a.re, a.im)); return cd_make(creal(q), cimag(q)); }
+/* std::pow(const complex<double>&, const double&) as libstdc++ writes it. */
+static cd cd_pow(cd x, double y)
+{
+    if (x.im == 0.0 && x.re > 0.0) return cd_make(pow(x.re, y), 0.0);
+    double complex t = clog(CMPLX(x.re, x.im));
+    double rho = exp(y * creal(t)), theta = y * cimag(t);
+    return cd_make(rho * cos(theta), rho * sin(theta));                          /* std::polar */
+}
+
+/* P3p.cpp:238-293 */
+int orc_p3p_solve_quartic(const double factors[5], double roots[4])
+{
+    double A = factors[0], B = factors[1], C = factors[2], D = factors[3], E = factors[4];
+    double A_pw2 = A * A, B_pw2 = B * B, A_pw3 = A_pw2 * A, B_pw3 = B_pw2 * B, A_pw4 = A_pw3 * A, B_pw4 = B_pw3 * B;
+    double alpha = -3 * B_pw2 / (8 * A_pw2) + C / A;
+    double beta = B_pw3 / (8 * A_pw3) - B * C / (2 * A_pw2) + D / A;
+    double gamma = -3 * B_pw4 / (256 * A_pw4) + B_pw2 * C / (16 * A_pw3) - B * D / (4 * A_pw2) + E / A;
+    double alpha_pw2 = alpha * alpha, alpha_pw3 = alpha_pw2 * alpha;
+    cd P = cd_make(-alpha_pw2 / 12 - gamma, 0);
+    cd Q = cd_make(-alpha_pw3 / 108 + alpha * gamma / 3 - pow(beta, 2) / 8, 0);
+    cd R = cd_add(cd_divs(cd_neg(Q), 2.0), cd_sqrt(cd_add(cd_divs(cd_pow(Q, 2.0), 4.0), cd_divs(cd_pow(P, 3.0), 27.0))));
+    cd U = cd_pow(R, 1.0 / 3.0);
+    cd y;
+    if (U.re == 0)
+        y = cd_rsub(-5.0 * alpha / 6.0, cd_pow(Q, 1.0 / 3.0));
+    else
+        y = cd_add(cd_rsub(-5.0 * alpha / 6.0, cd_div(P, cd_scale(U, 3.0))), U);
+    cd w = cd_sqrt(cd_adds(cd_scale(y, 2.0), alpha));
+    cd two_beta_w = cd_div(cd_make(2.0 * beta, 0), w);
+    cd base = cd_adds(cd_scale(y, 2.0), 3.0 * alpha);
+    cd s_plus = cd_sqrt(cd_neg(cd_add(base, two_beta_w)));
+    cd s_minus = cd_sqrt(cd_neg(cd_sub(base, two_beta_w)));
+    double shift = -B / (4.0 * A);
+    roots[0] = cd_adds(cd_scale(cd_add(w, s_plus), 0.5), shift).re;
+    roots[1] = cd_adds(cd_scale(cd_sub(w, s_plus), 0.5), shift).re;
+    roots[2] = cd_adds(cd_scale(cd_add(cd_neg(w), s_minus), 0.5), shift).re;
+    roots[3] = cd_adds(cd_scale(cd_sub(cd_neg(w), s_minus), 0.5), shift).re;
+    return 0;
+}
+
+static void v_cross(const double a[3], const double b[3], double c[3])
+{
+    c[0] = a[1] * b[2] - a[2] * b[1]; c[1] = a[2] * b[0] - a[0] * b[2]; c[2] = a[0] * b[1] - a[1] * b[0];
+}
+static double v_dot(const double a[3], const double b[3]) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+static double v_norm(const double a[3]) { return sqrt(v_dot(a, a)); }
+static void m_vec(const double M[9], const double v[3], double o[3])
+{
+    for (int r = 0; r < 3; ++r) o[r] = M[3 * r] * v[0] + M[3 * r + 1] * v[1] + M[3 * r + 2] * v[2];
+}
+
+/* P3p.cpp:64-236 */
+int orc_p3p_compute_poses(const double fcols[9], const double pcols[9], double sol[48])
+{
+    double P1[3], P2[3], P3[3], f1[3], f2[3], f3[3], t1[3], t2[3], cr[3];
+    memcpy(P1, pcols, 24); memcpy(P2, pcols + 3, 24); memcpy(P3, pcols + 6, 24);
+    for (int k = 0; k < 3; ++k) { t1[k] = P2[k] - P1[k]; t2[k] = P3[k] - P1[k]; }
+    v_cross(t1, t2, cr);
+    if (v_norm(cr) == 0) return -1;
+    memcpy(f1, fcols, 24); memcpy(f2, fcols + 3, 24); memcpy(f3, fcols + 6, 24);
+    double T[9], e1[3], e2[3], e3[3], tmp[3];
+    for (int pass = 0; pass < 2; ++pass) {
+        memcpy(e1, f1, 24);
+        v_cross(f1, f2, e3);
+        double n = v_norm(e3);
+        for (int k = 0; k < 3; ++k) e3[k] = e3[k] / n;
+        v_cross(e3, e1, e2);
+        memcpy(T, e1, 24); memcpy(T + 3, e2, 24); memcpy(T + 6, e3, 24);
+        m_vec(T, f3, tmp);
+        memcpy(f3, tmp, 24);
+        if (pass == 0 && f3[2] > 0) {                                            /* :103-122 */
+            memcpy(f1, fcols + 3, 24); memcpy(f2, fcols, 24); memcpy(f3, fcols + 6, 24);
+            memcpy(P1, pcols + 3, 24); memcpy(P2, pcols, 24); memcpy(P3, pcols + 6, 24);
+            continue;
+        }
+        break;
+    }
+    double n1[3], n2[3], n3[3], N[9], d[3];
+    for (int k = 0; k < 3; ++k) n1[k] = P2[k] - P1[k];
+    { double n = v_norm(n1); for (int k = 0; k < 3; ++k) n1[k] = n1[k] / n; }
+    for (int k = 0; k < 3; ++k) d[k] = P3[k] - P1[k];
+    v_cross(n1, d, n3);
+    { double n = v_norm(n3); for (int k = 0; k < 3; ++k) n3[k] = n3[k] / n; }
+    v_cross(n3, n1, n2);
+    memcpy(N, n1, 24); memcpy(N + 3, n2, 24); memcpy(N + 6, n3, 24);
+    m_vec(N, d, tmp);
+    memcpy(P3, tmp, 24);
+    for (int k = 0; k < 3; ++k) d[k] = P2[k] - P1[k];
+    double d_12 = v_norm(d);
+    double f_1 = f3[0] / f3[2], f_2 = f3[1] / f3[2], p_1 = P3[0], p_2 = P3[1];
+    double cos_beta = v_dot(f1, f2);
+    double b = 1 / (1 - pow(cos_beta, 2)) - 1;
+    b = cos_beta < 0 ? -sqrt(b) : sqrt(b);
+    double f_1_pw2 = pow(f_1, 2), f_2_pw2 = pow(f_2, 2), p_1_pw2 = pow(p_1, 2), p_1_pw3 = p_1_pw2 * p_1,
+           p_1_pw4 = p_1_pw3 * p_1, p_2_pw2 = pow(p_2, 2), p_2_pw3 = p_2_pw2 * p_2, p_2_pw4 = p_2_pw3 * p_2,
+           d_12_pw2 = pow(d_12, 2), b_pw2 = pow(b, 2);
+    double factors[5];
+    factors[0] = -f_2_pw2 * p_2_pw4 - p_2_pw4 * f_1_pw2 - p_2_pw4;
+    factors[1] = 2 * p_2_pw3 * d_12 * b + 2 * f_2_pw2 * p_2_pw3 * d_12 * b - 2 * f_2 * p_2_pw3 * f_1 * d_12;
+    factors[2] = -f_2_pw2 * p_2_pw2 * p_1_pw2 - f_2_pw2 * p_2_pw2 * d_12_pw2 * b_pw2 - f_2_pw2 * p_2_pw2 * d_12_pw2
+               + f_2_pw2 * p_2_pw4 + p_2_pw4 * f_1_pw2 + 2 * p_1 * p_2_pw2 * d_12
+               + 2 * f_1 * f_2 * p_1 * p_2_pw2 * d_12 * b - p_2_pw2 * p_1_pw2 * f_1_pw2
+               + 2 * p_1 * p_2_pw2 * f_2_pw2 * d_12 - p_2_pw2 * d_12_pw2 * b_pw2 - 2 * p_1_pw2 * p_2_pw2;
+    factors[3] = 2 * p_1_pw2 * p_2 * d_12 * b + 2 * f_2 * p_2_pw3 * f_1 * d_12 - 2 * f_2_pw2 * p_2_pw3 * d_12 * b
+               - 2 * p_1 * p_2 * d_12_pw2 * b;
+    factors[4] = -2 * f_2 * p_2_pw2 * f_1 * p_1 * d_12 * b + f_2_pw2 * p_2_pw2 * d_12_pw2 + 2 * p_1_pw3 * d_12
+               - p_1_pw2 * d_12_pw2 + f_2_pw2 * p_2_pw2 * p_1_pw2 - p_1_pw4 - 2 * f_2_pw2 * p_2_pw2 * p_1 * d_12
+               + p_2_pw2 * f_1_pw2 * p_1_pw2 + f_2_pw2 * p_2_pw2 * d_12_pw2 * b_pw2;
+    double roots[4];
+    orc_p3p_solve_quartic(factors, roots);
+    for (int i = 0; i < 4; ++i) {
+        double cot_alpha = (-f_1 * p_1 / f_2 - roots[i] * p_2 + d_12 * b) / (-f_1 * roots[i] * p_2 / f_2 + p_1 - d_12);
+        double cos_theta = roots[i];
+        double sin_theta = sqrt(1 - pow(roots[i], 2));
+        double sin_alpha = sqrt(1 / (pow(cot_alpha, 2) + 1));
+        double cos_alpha = sqrt(1 - pow(sin_alpha, 2));
+        if (cot_alpha < 0) cos_alpha = -cos_alpha;
+        double Cl[3] = {d_12 * cos_alpha * (sin_alpha * b + cos_alpha),
+                        cos_theta * d_12 * sin_alpha * (sin_alpha * b + cos_alpha),
+                        sin_theta * d_12 * sin_alpha * (sin_alpha * b + cos_alpha)};
+        double *o = sol + 12 * i;
+        for (int r = 0; r < 3; ++r) o[r] = P1[r] + (N[r] * Cl[0] + N[3 + r] * Cl[1] + N[6 + r] * Cl[2]);  /* P1 + N^T C */
+        double Rl[9] = {-cos_alpha, -sin_alpha * cos_theta, -sin_alpha * sin_theta,
+                        sin_alpha, -cos_alpha * cos_theta, -cos_alpha * sin_theta,
+                        0, -sin_theta, cos_theta};
+        /* R = N^T * Rl^T * T : evaluate (N^T Rl^T) first, as Eigen's left-to-right product does */
+        double NR[9];
+        for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c)
+            NR[3 * r + c] = N[r] * Rl[3 * c] + N[3 + r] * Rl[3 * c + 1] + N[6 + r] * Rl[3 * c + 2];
+        for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c)
+            o[3 + 3 * r + c] = NR[3 * r] * T[c] + NR[3 * r + 1] * T[3 + c] + NR[3 * r + 2] * T[6 + c];
+    }
+    return 0;
+}
+
+/* ===================================================================================== */
+/* P4Pf in double and long double                                                         */
+/* ===================================================================================== */
+#define REAL double
+#define CPLX double complex
+#define FN(name) name##_d
+#define R_SQRT sqrt
+#define R_FABS fabs
+#define R_POW2(x) pow((x), 2)
+#define C_ABS cabs
+#define C_SQRT csqrt
+#define C_CONJ conj
+#define C_REAL creal
+#define C_IMAG cimag
+#define R_EPS 2.220446049250313e-16
+#include "p4pf_core.inc"
+#undef REAL
+#undef CPLX
+#undef FN
+#undef R_SQRT
+#undef R_FABS
+#undef R_POW2
+#undef C_ABS
+#undef C_SQRT
+#undef C_CONJ
+#undef C_REAL
+#undef C_IMAG
+#undef R_EPS
+
+#define REAL long double
+#define CPLX long double complex
+#define FN(name) name##_ld
+#define R_SQRT sqrtl
+#define R_FABS fabsl
+#define R_POW2(x) ((x) * (x))
+#define C_ABS cabsl
+#define C_SQRT csqrtl
+#define C_CONJ conjl
+#define C_REAL creall
+#define C_IMAG cimagl
+#define R_EPS 1.0842021724855044e-19L
+#include "p4pf_core.inc"
+
+int orc_p4pf(const double m2d[8], const double M3D[12], double f[10], double R[90], double t[30])
+{
+    return p4pf_m_d(m2d, M3D, f, R, t, NULL, NULL, NULL);
+}
+int orc_p4pf_ld(const double m2d[8], const double M3D[12], double f[10], double R[90], double t[30])
+{
+    return p4pf_m_ld(m2d, M3D, f, R, t, NULL, NULL, NULL);
+}
+int orc_p4pf_stages(const double m2d[8], const double M3D[12], double coefs[42], double A[100], double roots[40])
+{
+    return p4pf_m_d(m2d, M3D, NULL, NULL, NULL, coefs, A, roots);
+}
+
+/* ===================================================================================== */
+/* projection + scoring                                                                   */
+/* ===================================================================================== */
+/* query_loader.cpp:222-254.  The reference inverts the 4x4 [Rc C; 0 1] with Eigen's general
+ * inverse; for that block form the inverse is [Rc^-1, -Rc^-1 C; 0 1], evaluated here with
+ * the cofactor (adjugate / determinant) inverse of Rc. */
+void orc_compute_matrices(double focal, const double C[3], const double Rc[9], double P[12])
+{
+    double a = Rc[0], b = Rc[1], c = Rc[2], d = Rc[3], e = Rc[4], f = Rc[5], g = Rc[6], h = Rc[7], i = Rc[8];
+    double det = a * (e * i - f * h) - b * (d * i - f * g) + c * (d * h - e * g);
+    double inv[9] = {(e * i - f * h) / det, (c * h - b * i) / det, (b * f - c * e) / det,
+                     (f * g - d * i) / det, (a * i - c * g) / det, (c * d - a * f) / det,
+                     (d * h - e * g) / det, (b * g - a * h) / det, (a * e - b * d) / det};
+    double K[3] = {focal, focal, 1.0};
+    for (int r = 0; r < 3; ++r) {
+        for (int cidx = 0; cidx < 3; ++cidx) P[4 * r + cidx] = K[r] * inv[3 * r + cidx];
+        P[4 * r + 3] = K[r] * -(inv[3 * r] * C[0] + inv[3 * r + 1] * C[1] + inv[3 * r + 2] * C[2]);
+    }
+}
+
+/* query_processor.cpp:46-124 */
+int orc_score(const double P[12], int n, const float *kx, const float *ky, const float *X, const float *Y,
+              const float *Z, int width, int height, double eps, uint8_t *mask)
+{
+    int count = 0;
+    for (int i = 0; i < n; ++i) {
+        double x = X[i], y = Y[i], z = Z[i];
+        double p0 = P[0] * x + P[1] * y + P[2] * z + P[3] * 1.0;
+        double p1 = P[4] * x + P[5] * y + P[6] * z + P[7] * 1.0;
+        double p2 = P[8] * x + P[9] * y + P[10] * z + P[11] * 1.0;
+        double u = -(kx[i] - (double)width / 2.0), v = -(ky[i] - (double)height / 2.0);
+        double du = u - p0 / p2, dv = v - p1 / p2;
+        double dist = sqrt(du * du + dv * dv);
+        int in = dist < eps;
+        if (mask) mask[i] = (uint8_t)in;
+        count += in;
+    }
+    return count;
+}
+
+/* query_processor.cpp:126-169 */
+int64_t orc_coverage_area(int n, const float *kx, const float *ky, const uint8_t *mask, int width, int height)
+{
+    if (width <= 0 || height <= 0) return 0;
+    uint8_t *map = (uint8_t *)calloc((size_t)width * height, 1);
+    int cover = (int)ceilf((float)width / 20.0f);                   /* std::ceil((float)w / 20.0) */
+    for (int i = 0; i < n; ++i) {
+        if (mask && !mask[i]) continue;
+        int x = (int)rintf(kx[i]), y = (int)rintf(ky[i]);
+#define CLAMP(v, hi) ((v) < 0 ? 0 : ((v) > (hi) ? (hi) : (v)))
+        int sx = CLAMP(x - cover / 2, width - 1), sy = CLAMP(y - cover / 2, height - 1);
+        int ex = CLAMP(x + cover / 2, width - 1), ey = CLAMP(y + cover / 2, height - 1);
+#undef CLAMP
+        if (sy < ey && sx < ex)
+            for (int r = sy; r < ey; ++r) memset(map + (size_t)r * width + sx, 1, (size_t)(ex - sx));
+    }
+    int64_t area = 0;
+    for (size_t i = 0; i < (size_t)width * height; ++i) area += map[i];
+    free(map);
+    return area;
+}
+
+/* ===================================================================================== */
+/* counter-based sampling                                                                 */
+/* ===================================================================================== */
+void orc_philox4x32(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4])
+{
+    uint32_t c0 = ctr[0], c1 = ctr[1], c2 = ctr[2], c3 = ctr[3], k0 = key[0], k1 = key[1];
+    for (int r = 0; r < 10; ++r) {
+        uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+uint32_t orc_draw(uint64_t seed, uint32_t query, uint32_t hyp, uint32_t stream, uint32_t k)
+{
+    uint32_t ctr[4] = {hyp, k >> 2, query, stream}, key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)}, out[4];
+    orc_philox4x32(ctr, key, out);
+    return out[k & 3];
+}
+
+static uint32_t draw_index(uint64_t seed, uint32_t query, uint32_t hyp, uint32_t k, uint32_t n)
+{
+    return (uint32_t)(((uint64_t)orc_draw(seed, query, hyp, 0, k) * n) >> 32);
+}
+
+/* query_processor_basic.cpp:136-152 */
+int orc_sample_basic(uint64_t seed, uint32_t query, uint32_t hyp, int m, uint32_t n, const uint32_t *lindex,
+                     uint32_t out[4])
+{
+    uint32_t k = 0;
+    for (int i = 0; i < m; ++i) {
+        for (;;) {
+            uint32_t idx = draw_index(seed, query, hyp, k++, n);
+            int valid = 1;
+            for (int j = 0; j < i; ++j) {
+                uint32_t a = lindex ? lindex[idx] : idx, b = lindex ? lindex[out[j]] : out[j];
+                if (a == b) valid = 0;
+            }
+            if (valid) { out[i] = idx; break; }
+        }
+    }
+    return (int)k;
+}
+
+/* sigmoid pre-multiplier 1/(1+exp(-(cs/5))) of query_processor_advanced.cpp:391-392:
+ * float division, then double exp. */
+static double coocc_gain(uint32_t cs) { return 1.0 / (1.0 + exp(-(double)((float)cs / 5.0f))); }
+
+/* query_processor_advanced.cpp:329-440 */
+int orc_sample_advanced(uint64_t seed, uint32_t query, uint32_t hyp, int m, uint32_t n, const uint32_t *lindex,
+                        const uint32_t *cam_off, const uint32_t *cam_ids, uint32_t out[4], int *nprob)
+{
+    int any5 = 0;
+    for (uint32_t i = 0; i < n && !any5; ++i) any5 = cam_off[i + 1] - cam_off[i] >= 5;
+    if (!any5) return -1;
+    uint32_t k = 0, kp = 0;
+    uint32_t inter[4096], check[4096];
+    uint32_t ninter = 0;
+    int zero_check_count = 0;
+    const int zero_check_limit = 200;
+    int nsel = 0;
+    for (int i = 0; i < m; ++i) {
+        int valid = 0, zero_check = 0;
+        while (!valid) {
+            uint32_t idx, cb, ce;
+            do {
+                idx = draw_index(seed, query, hyp, k++, n);
+                cb = cam_off[idx]; ce = cam_off[idx + 1];
+                if (i == 0) { ninter = ce - cb; memcpy(inter, cam_ids + cb, ninter * 4u); }
+            } while (i == 0 && ce - cb < 5);
+            valid = 1;
+            for (int j = 0; j < nsel; ++j) {
+                uint32_t a = lindex ? lindex[idx] : idx, b = lindex ? lindex[out[j]] : out[j];
+                if (a == b) valid = 0;
+            }
+            uint32_t ncheck = 0;
+            if (valid && i > 0) {
+                uint32_t p = cb, q = 0;
+                while (p < ce && q < ninter) {
+                    if (cam_ids[p] < inter[q]) ++p;
+                    else if (inter[q] < cam_ids[p]) ++q;
+                    else { check[ncheck++] = inter[q]; ++p; ++q; }
+                }
+                if (ncheck == 0 && zero_check_count <= zero_check_limit) {
+                    zero_check++;
+                    valid = 0;
+                } else {
+                    uint32_t mn = ninter < ce - cb ? ninter : ce - cb;
+                    float ratio = (float)ncheck / (float)mn;
+                    ratio = (float)((double)ratio * coocc_gain(ncheck));
+                    float temp = (float)(orc_draw(seed, query, hyp, 1, kp++) >> 8) * (1.0f / 16777216.0f);
+                    if (zero_check_count > zero_check_limit) ratio = 1.0f;
+                    if (ratio > temp) { valid = 1; ninter = ncheck; memcpy(inter, check, ncheck * 4u); }
+                    else valid = 0;
+                }
+            }
+            if (valid) out[nsel++] = idx;
+            if (zero_check > 30) {
+                i = -1; nsel = 0; ninter = 0; valid = 1; zero_check_count++;
+            }
+        }
+    }
+    if (nprob) *nprob = (int)kp;
+    return (int)k;
+}
+
+/* ===================================================================================== */
+/* RANSAC loop (query_processor_basic.cpp:105-293; advanced variant differs only in       */
+/* max_steps / early_exit, query_processor_advanced.cpp:296-327,445-581)                  */
+/* ===================================================================================== */
+int orc_ransac(const orc_query *q, const orc_ransac_params *p, const uint32_t *samples, unsigned nsamples,
+               orc_ransac_result *res, uint8_t *best_mask)
+{
+    memset(res, 0, sizeof *res);
+    int p4pfmode = q->focal == 0.0;
+    unsigned hyposet = 0, steps = 0;
+    double hypoquality = 0;
+    int64_t best_key = 0;                 /* count or A_f of the kept pose */
+    int64_t area_all = p->select_coverage ? orc_coverage_area(q->n, q->kx, q->ky, NULL, q->width, q->height) : 0;
+    res->area_all = area_all;
+    uint8_t *mask = (uint8_t *)malloc((size_t)q->n);
+    const double hw = (double)q->width / 2.0, hh = (double)q->height / 2.0;
+    while (steps < p->max_steps && steps < nsamples &&
+           (!p->early_exit || (hyposet < (unsigned)q->n / p->inlier_divisor && hyposet < p->inlier_absolute))) {
+        const uint32_t *s = samples + 4 * (size_t)steps;
+        int nsol = 0;
+        double fs[10], Cs[30], Rcs[90];
+        if (p4pfmode) {
+            double m2d[8], M3D[12], f[10], R[90], t[30];
+            for (int i = 0; i < 4; ++i) {
+                m2d[2 * i] = -(q->kx[s[i]] - hw); m2d[2 * i + 1] = -(q->ky[s[i]] - hh);
+                M3D[3 * i] = q->X[s[i]]; M3D[3 * i + 1] = q->Y[s[i]]; M3D[3 * i + 2] = q->Z[s[i]];
+            }
+            nsol = orc_p4pf(m2d, M3D, f, R, t);
+            if (nsol < 0) nsol = 0;
+            for (int k = 0; k < nsol; ++k) {                                      /* basic.cpp:195-198 */
+                fs[k] = f[k];
+                for (int r = 0; r < 3; ++r) {
+                    Cs[3 * k + r] = -(R[9 * k + r] * t[3 * k] + R[9 * k + 3 + r] * t[3 * k + 1] + R[9 * k + 6 + r] * t[3 * k + 2]);
+                    for (int c = 0; c < 3; ++c) Rcs[9 * k + 3 * r + c] = R[9 * k + 3 * c + r];
+                }
+            }
+        } else {
+            double fc[9], pc[9], sol[48];
+            for (int i = 0; i < 3; ++i) {
+                double v[3] = {-(q->kx[s[i]] - hw), -(q->ky[s[i]] - hh), q->focal};
+                double nv = v_norm(v);
+                for (int k = 0; k < 3; ++k) fc[3 * i + k] = v[k] / nv;
+                pc[3 * i] = q->X[s[i]]; pc[3 * i + 1] = q->Y[s[i]]; pc[3 * i + 2] = q->Z[s[i]];
+            }
+            /* collinear world points: the reference scores uninitialised memory
+             * (P3p.cpp:78-79, basic.cpp:257-264); normalised here to "no solutions". */
+            if (orc_p3p_compute_poses(fc, pc, sol) == 0) {
+                nsol = 4;
+                for (int k = 0; k < 4; ++k) { fs[k] = q->focal; memcpy(Cs + 3 * k, sol + 12 * k, 24); memcpy(Rcs + 9 * k, sol + 12 * k + 3, 72); }
+            }
+        }
+        for (int k = 0; k < nsol; ++k) {
+            double P[12];
+            orc_compute_matrices(fs[k], Cs + 3 * k, Rcs + 9 * k, P);
+            int cnt = orc_score(P, q->n, q->kx, q->ky, q->X, q->Y, q->Z, q->width, q->height, p->eps, mask);
+            res->poses_scored++;
+            int better;
+            int64_t key;
+            if (p->select_coverage) {
+                key = cnt > 0 ? orc_coverage_area(q->n, q->kx, q->ky, mask, q->width, q->height) : 0;
+                float qf = (float)key / (float)area_all;                         /* query_processor.cpp:171-174 */
+                better = (double)qf > hypoquality;
+                if (better) hypoquality = (double)qf;
+            } else {
+                key = cnt;
+                better = key > best_key;
+            }
+            if (better) {
+                best_key = key; hyposet = (unsigned)cnt;
+                res->found = 1; res->focal = fs[k];
+                memcpy(res->C, Cs + 3 * k, 24); memcpy(res->Rc, Rcs + 9 * k, 72);
+                res->hyposet = hyposet; res->area_fit = p->select_coverage ? key : 0;
+                res->best_step = steps; res->best_sol = (unsigned)k;
+                if (best_mask) memcpy(best_mask, mask, (size_t)q->n);
+            }
+        }
+        ++steps;
+    }
+    res->steps = steps;
+    free(mask);
+    return 0;
+}
