@@ -1,0 +1,135 @@
+/*
+ * pose_amd.h -- C ABI of the MI355X RANSAC pose-hypothesis library (libpose_amd.so).
+ *
+ * The reference (naibaf7/pose_estimation) has no FFI layer; its seam is the C++ class
+ * interface of P3p, P4pf and QueryProcessor.  Each entry point below names the reference
+ * interface it stands in for.  Plain pointers and sizes only; every function returns an
+ * int status (0 = ok, negative = error, message via pose_amd_last_error) and never throws.
+ * All pointer arguments are HOST pointers unless the name ends in _dev.  A context is
+ * bound to one GPU and one HIP stream and is not thread-safe (one host thread per GPU).
+ *
+ * Conventions (same as the reference):
+ *   keypoints kx,ky: float32 pixel coordinates, origin top-left (SIFT_keypoint.hpp:38-41);
+ *   observation used by the solvers/scoring: u = -(kx - w/2), v = -(ky - h/2)
+ *     (query_processor_basic.cpp:173-175, query_processor.cpp:111-112);
+ *   world points X,Y,Z: float32 (parse_bundler.hpp:54);
+ *   P3P pose = (C, Rc) camera centre and cam->world rotation (P3p.hpp:37-43);
+ *   P4Pf pose = (f, R, t) with lambda*m = diag(f,f,1) [R t] M  (P4pf.cpp:273-275);
+ *   3x3 matrices row-major.
+ */
+#ifndef POSE_AMD_H
+#define POSE_AMD_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct pose_amd_ctx pose_amd_ctx;
+
+enum { POSE_AMD_OK = 0, POSE_AMD_EINVAL = -1, POSE_AMD_EHIP = -2, POSE_AMD_ENOMEM = -3, POSE_AMD_ESTATE = -4 };
+enum { POSE_AMD_SOLVER_P3P = 0, POSE_AMD_SOLVER_P4PF = 1 };
+enum { POSE_AMD_SAMPLE_BASIC = 0, POSE_AMD_SAMPLE_ADVANCED = 1 };
+enum { POSE_AMD_SELECT_INLIERS = 0, POSE_AMD_SELECT_COVERAGE = 1 };
+#define POSE_AMD_P3P_MAXSOL 4
+#define POSE_AMD_P4PF_MAXSOL 10
+
+/* ---- context ------------------------------------------------------------------------ */
+int pose_amd_create(int device, pose_amd_ctx **out);
+void pose_amd_destroy(pose_amd_ctx *ctx);
+const char *pose_amd_last_error(const pose_amd_ctx *ctx);   /* ctx may be NULL: creation errors */
+int pose_amd_device_info(const pose_amd_ctx *ctx, char *name, int name_len, int *compute_units, int *clock_khz);
+int pose_amd_synchronize(pose_amd_ctx *ctx);
+
+/* ---- minimal solvers, batched (parity entry points) ----------------------------------- */
+/* Replaces P3p::computePoses (P3p.hpp:59, P3p.cpp:64-236) for `count` independent problems.
+ * fcols/pcols: per problem 3 vectors of 3 doubles (unit bearings / world points).
+ * sol: per problem 4 x {C[3], Rc[9]} = 48 doubles.  status[i] = 0 or -1 (collinear world
+ * points; the 48 outputs are then NaN). */
+int pose_amd_p3p_batch(pose_amd_ctx *ctx, int count, const double *fcols, const double *pcols, double *sol,
+                       int *status);
+/* P3p::solveQuartic (P3p.hpp:60, P3p.cpp:238-293): factors[5] -> roots[4] per problem. */
+int pose_amd_quartic_batch(pose_amd_ctx *ctx, int count, const double *factors, double *roots);
+/* Replaces P4pf::P4Pf_m (P4pf.hpp:39, P4pf.cpp:286-507) for `count` problems.
+ * m2d: 4 x (x,y) per problem; M3D: 4 x (X,Y,Z).  nsol[i] in 0..10, or -1 where the
+ * reference returns -1.  f: 10, R: 90, t: 30 doubles per problem, solutions ordered by
+ * ascending zd (depth of the 4th point relative to the 1st). */
+int pose_amd_p4pf_batch(pose_amd_ctx *ctx, int count, const double *m2d, const double *M3D, int *nsol, double *f,
+                        double *R, double *t);
+
+/* ---- query data (the good_matches list of QueryProcessor*::Process) -------------------- */
+/* Uploads one query's correspondences (stands in for the SiftMatch / SIFT_keypoint /
+ * point3D triple walk of query_processor.cpp:62-69).  lindex may be NULL (= 0..n-1).
+ * focal == 0 selects P4Pf as the reference does (query_processor_basic.cpp:103). */
+int pose_amd_set_query(pose_amd_ctx *ctx, int n, const float *kx, const float *ky, const float *X, const float *Y,
+                       const float *Z, const uint32_t *lindex, int width, int height, double focal);
+/* Camera sets of each correspondence in CSR form (SiftMatch::camset,
+ * query_processor_advanced.cpp:272-285): cam_off[n+1], sorted ids. */
+int pose_amd_set_camsets(pose_amd_ctx *ctx, const uint32_t *cam_off, const uint32_t *cam_ids);
+
+/* ---- projection + inlier test ------------------------------------------------------------ */
+/* Query::ComputeMatrices (query_loader.cpp:222-254) for `count` poses:
+ * focal[i], C[3i..], Rc[9i..] -> P[12i..] (3x4 row-major). */
+int pose_amd_compute_matrices_batch(pose_amd_ctx *ctx, int count, const double *focal, const double *C,
+                                    const double *Rc, double *P);
+/* QueryProcessor::Project + the inlier loop of TestHypothesis (query_processor.cpp:46-124)
+ * for `nposes` projection matrices against the current query.  counts[nposes];
+ * mask_words (may be NULL): nposes * ceil(n/64) words, bit j of word w = correspondence
+ * 64*w+j is an inlier. */
+int pose_amd_score_batch(pose_amd_ctx *ctx, int nposes, const double *P, double eps, int *counts,
+                         uint64_t *mask_words);
+/* Coverage areas of TestHypothesis (query_processor.cpp:126-169): area of the union of the
+ * coverage boxes of the inliers of each pose (areas[nposes]) and of all matches (*area_all). */
+int pose_amd_coverage_batch(pose_amd_ctx *ctx, int nposes, const double *P, double eps, int64_t *areas,
+                            int64_t *area_all);
+
+/* ---- sampling (replaces GetRandomSelector / GetRandomProbability, pose_utils.cpp:58-84) -- */
+/* Generates the ordered sample tuples of hypotheses [hyp_begin, hyp_begin+hyp_count) on the
+ * device with the counter-based generator (Philox4x32-10 keyed by seed, counter =
+ * (hyp, draw/4, query_id, stream)); draw k maps to index (u32 * n) >> 32.  BASIC follows
+ * query_processor_basic.cpp:136-152, ADVANCED query_processor_advanced.cpp:329-440.
+ * The tuples stay resident for pose_amd_ransac_run and are exported to samples_out
+ * (hyp_count x 4 uint32, unused 4th entry = 0xFFFFFFFF for P3P) when it is not NULL. */
+int pose_amd_sample(pose_amd_ctx *ctx, int sample_mode, uint64_t seed, uint32_t query_id, uint32_t hyp_begin,
+                    uint32_t hyp_count, uint32_t *samples_out);
+/* Explicit tuples instead (e.g. ones exported earlier, or the reference's own draws). */
+int pose_amd_set_samples(pose_amd_ctx *ctx, const uint32_t *samples, uint32_t hyp_count);
+
+/* ---- RANSAC over the resident samples (QueryProcessorBasic/Advanced::Process loops) ------ */
+typedef struct {
+    int select_mode;        /* POSE_AMD_SELECT_* ; COVERAGE is the reference's criterion         */
+    double eps;             /* inlier threshold in px, reference 0.5 (basic.cpp:109)             */
+    int early_exit;         /* 1: stop like basic.cpp:132-133; 0: run all (advanced.cpp:327)     */
+    uint32_t inlier_divisor;  /* 10 */
+    uint32_t inlier_absolute; /* 12 */
+} pose_amd_params;
+
+typedef struct {
+    int found;              /* 0 when no pose had a positive score                               */
+    double focal, C[3], Rc[9];   /* what Process writes back into Query (basic.cpp:221-224)      */
+    uint32_t inliers;       /* hyposet of the kept pose                                          */
+    int64_t area_fit, area_all;  /* coverage mode only                                           */
+    uint32_t steps;         /* RANSAC steps consumed (== hyp_count without early exit)            */
+    uint32_t best_hyp, best_sol; /* index of the kept pose within the resident samples           */
+    uint64_t poses_scored;
+} pose_amd_result;
+
+/* Runs solve + score (+ coverage) + selection over the resident sample tuples, in
+ * sequential-equivalent order: the kept pose is the first one that is strictly better than
+ * all earlier ones, and with early_exit the loop stops after the first step at which the
+ * kept pose has >= min(n/inlier_divisor, inlier_absolute) inliers.
+ * nsol_out (hyp_count) / counts_out (hyp_count * maxsol) may be NULL. */
+int pose_amd_ransac_run(pose_amd_ctx *ctx, const pose_amd_params *params, pose_amd_result *result, int *nsol_out,
+                        int *counts_out);
+/* Inlier mask (n bytes, 0/1) of the pose kept by the last pose_amd_ransac_run
+ * (fitted_matches, basic.cpp:224). */
+int pose_amd_best_mask(pose_amd_ctx *ctx, uint8_t *mask);
+
+/* ---- measurement -------------------------------------------------------------------------- */
+/* Kernel time of the last pose_amd_ransac_run measured with HIP events on the context's
+ * stream: ms[0] solve, ms[1] score, ms[2] select/reduce, ms[3] whole call (device side). */
+int pose_amd_last_timing(pose_amd_ctx *ctx, float ms[4]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,75 @@
+"""ctypes binding of libpose_amd.so (the C ABI declared in include/pose_amd.h).
+
+There is no fallback: if the shared library is missing or a call fails, an exception is
+raised.  Nothing here computes on the CPU.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpose_amd.so")
+
+
+class PoseAmdError(RuntimeError):
+    pass
+
+
+class Params(C.Structure):
+    _fields_ = [("select_mode", C.c_int), ("eps", C.c_double), ("early_exit", C.c_int),
+                ("inlier_divisor", C.c_uint32), ("inlier_absolute", C.c_uint32)]
+
+
+class Result(C.Structure):
+    _fields_ = [("found", C.c_int), ("focal", C.c_double), ("C", C.c_double * 3), ("Rc", C.c_double * 9),
+                ("inliers", C.c_uint32), ("area_fit", C.c_int64), ("area_all", C.c_int64), ("steps", C.c_uint32),
+                ("best_hyp", C.c_uint32), ("best_sol", C.c_uint32), ("poses_scored", C.c_uint64)]
+
+
+_dp = C.POINTER(C.c_double)
+_fp = C.POINTER(C.c_float)
+_ip = C.POINTER(C.c_int)
+_up = C.POINTER(C.c_uint32)
+_u8 = C.POINTER(C.c_uint8)
+_u64 = C.POINTER(C.c_uint64)
+_i64 = C.POINTER(C.c_int64)
+_ctx = C.c_void_p
+
+# name -> (restype, argtypes); must list every function include/pose_amd.h declares
+SIGNATURES = {
+    "pose_amd_create": (C.c_int, [C.c_int, C.POINTER(_ctx)]),
+    "pose_amd_destroy": (None, [_ctx]),
+    "pose_amd_last_error": (C.c_char_p, [_ctx]),
+    "pose_amd_device_info": (C.c_int, [_ctx, C.c_char_p, C.c_int, _ip, _ip]),
+    "pose_amd_synchronize": (C.c_int, [_ctx]),
+    "pose_amd_p3p_batch": (C.c_int, [_ctx, C.c_int, _dp, _dp, _dp, _ip]),
+    "pose_amd_quartic_batch": (C.c_int, [_ctx, C.c_int, _dp, _dp]),
+    "pose_amd_p4pf_batch": (C.c_int, [_ctx, C.c_int, _dp, _dp, _ip, _dp, _dp, _dp]),
+    "pose_amd_set_query": (C.c_int, [_ctx, C.c_int, _fp, _fp, _fp, _fp, _fp, _up, C.c_int, C.c_int, C.c_double]),
+    "pose_amd_set_camsets": (C.c_int, [_ctx, _up, _up]),
+    "pose_amd_compute_matrices_batch": (C.c_int, [_ctx, C.c_int, _dp, _dp, _dp, _dp]),
+    "pose_amd_score_batch": (C.c_int, [_ctx, C.c_int, _dp, C.c_double, _ip, _u64]),
+    "pose_amd_coverage_batch": (C.c_int, [_ctx, C.c_int, _dp, C.c_double, _i64, _i64]),
+    "pose_amd_sample": (C.c_int, [_ctx, C.c_int, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, _up]),
+    "pose_amd_set_samples": (C.c_int, [_ctx, _up, C.c_uint32]),
+    "pose_amd_ransac_run": (C.c_int, [_ctx, C.POINTER(Params), C.POINTER(Result), _ip, _ip]),
+    "pose_amd_best_mask": (C.c_int, [_ctx, _u8]),
+    "pose_amd_last_timing": (C.c_int, [_ctx, C.POINTER(C.c_float)]),
+}
+
+_lib = None
+
+
+def load():
+    """Loads libpose_amd.so and declares every prototype.  Raises if the library is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise PoseAmdError(f"{LIB_PATH} not found: build it with `make` (hipcc --offload-arch=gfx950)")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib

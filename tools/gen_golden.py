@@ -1,0 +1,90 @@
+#!/usr/bin/env python3
+"""Generates the committed fixtures under tests/golden/.
+
+score_threshold.json: a pose and 257 correspondences; several observations are moved to
+0.5 px +- {1e-3, 1e-4} (the finest steps float32 keypoints allow) around the threshold and
+the pose translation is then nudged so that one point sits within 1e-12 px of it.  The
+expected mask is computed in exact rational arithmetic (fractions.Fraction), not by the
+oracle, so it pins the oracle's comparison independently.
+
+p4pf_lapack.json: 40 random P4Pf problems with the roots (f, zb, zc, zd) obtained from the
+NumPy/LAPACK restatement in tests/np_ref.py.
+"""
+import json
+import os
+import sys
+from fractions import Fraction as Fr
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import np_ref            # noqa: E402
+import oracle_lib as O   # noqa: E402
+from pose_estimation_amd import synth   # noqa: E402
+
+
+def exact_mask(P, kx, ky, X, Y, Z, w, h):
+    Pf = [[Fr(float(v)) for v in row] for row in P]
+    out = []
+    for i in range(len(kx)):
+        x, y, z = Fr(float(X[i])), Fr(float(Y[i])), Fr(float(Z[i]))
+        p = [r[0] * x + r[1] * y + r[2] * z + r[3] for r in Pf]
+        u = -(Fr(float(kx[i])) - Fr(w, 2)); v = -(Fr(float(ky[i])) - Fr(h, 2))
+        if p[2] == 0:
+            out.append(0); continue
+        du, dv = u - p[0] / p[2], v - p[1] / p[2]
+        out.append(int(du * du + dv * dv < Fr(1, 4)))
+    return out
+
+
+def score_fixture():
+    q = synth.make_query(257, 0.5, 77, width=1024, height=768, focal=900.0, noise_px=0.45)
+    P = O.compute_matrices(q["f_true"], q["C_true"], q["Rc_true"])
+    kx, ky = q["kx"].copy(), q["ky"].copy()
+    X, Y, Z = q["X"], q["Y"], q["Z"]
+    idx = np.nonzero(q["inliers"])[0]
+    Xh = np.stack([X, Y, Z, np.ones_like(X)], 1).astype(np.float64)
+    pr = Xh @ P.T
+    up, vp = pr[:, 0] / pr[:, 2], pr[:, 1] / pr[:, 2]
+    for j, d in enumerate([0.5 - 1e-3, 0.5 + 1e-3, 0.5 - 1e-4, 0.5 + 1e-4, 0.499, 0.501]):
+        i = idx[j]
+        ang = 0.7 * (j + 1)
+        kx[i] = np.float32(q["width"] / 2.0 - (up[i] + d * np.cos(ang)))
+        ky[i] = np.float32(q["height"] / 2.0 - (vp[i] + d * np.sin(ang)))
+    # nudge the x translation so that point idx[6] lands 1e-12 px inside the threshold
+    i = idx[6]
+    u = -(float(kx[i]) - q["width"] / 2.0); v = -(float(ky[i]) - q["height"] / 2.0)
+    dv = v - vp[i]
+    target_du = np.sqrt(max(0.25 - dv * dv, 0.0)) - 1e-12
+    du = u - up[i]
+    P = P.copy()
+    P[0, 3] += (du - np.sign(du) * target_du) * pr[i, 2]
+    mask = exact_mask(P, kx, ky, X, Y, Z, q["width"], q["height"])
+    return dict(P=P.reshape(-1).tolist(), kx=kx.tolist(), ky=ky.tolist(), X=X.tolist(), Y=Y.tolist(), Z=Z.tolist(),
+                width=q["width"], height=q["height"], mask=mask)
+
+
+def p4pf_fixture():
+    m, M = synth.random_p4pf_problems(60, 1234)
+    out = []
+    for i in range(60):
+        n, k, A, roots = O.p4pf_stages(m[i], M[i])
+        if n < 0:
+            continue
+        ref, Aref = np_ref.roots_from_coefs(k)
+        if len(ref) != n or (n and np.abs(ref - roots).max() > 1e-7 * max(1, np.abs(ref).max())):
+            continue            # keep only cases where both linear-algebra stacks agree
+        out.append(dict(m2d=m[i].tolist(), M3D=M[i].tolist(), roots=ref.tolist()))
+        if len(out) == 40:
+            break
+    return out
+
+
+if __name__ == "__main__":
+    gd = os.path.join(ROOT, "tests", "golden")
+    os.makedirs(gd, exist_ok=True)
+    json.dump(score_fixture(), open(os.path.join(gd, "score_threshold.json"), "w"))
+    json.dump(p4pf_fixture(), open(os.path.join(gd, "p4pf_lapack.json"), "w"))
+    print("fixtures written")
