@@ -1,0 +1,151 @@
+#!/usr/bin/env python3
+"""Benchmark of the RANSAC pose-hypothesis hot path on MI355X.
+
+Workload (BASELINE.json configs[1]): one synthetic query with 4 000 2D-3D matches, 10 %
+inliers, unknown focal (P4Pf), 1 M hypotheses per step.  One step = sample 1 M minimal
+4-tuples on the device, solve P4Pf for each, score every returned pose against all 4 000
+correspondences, select the best pose.  Inputs are resident in HBM before the timed region.
+
+N > 1 GPUs (launched by torch.distributed.run, one rank per GPU): the hypothesis range is
+sharded, every rank evaluates its own 1 M hypotheses of the same query per step (weak
+scaling) and the packed (inlier count, ~hypothesis id) keys are max-all-reduced over RCCL.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+FP64_VECTOR_PEAK_TFLOPS = 78.6     # MI355X fp64 vector peak: 256 CU x 4 SIMD x 16 FMA lanes/clk x 2 x 2.4 GHz
+HBM_PEAK_GBS = 8000.0
+SCORE_FLOP_PER_PAIR = 28           # 11 FMA + 4 MUL + 1 compare per (pose, correspondence), see DESIGN.md
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--hyps", type=int, default=1 << 20, help="hypotheses per GPU per step")
+    ap.add_argument("--matches", type=int, default=4000)
+    ap.add_argument("--inlier-frac", type=float, default=0.10)
+    ap.add_argument("--cpu-hyps", type=int, default=0, help="CPU baseline sample size (0 = auto)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    elif args.gpus > 1:
+        print("bench.py: --gpus > 1 must be launched through torch.distributed.run", file=sys.stderr)
+        return 2
+
+    from pose_estimation_amd import Context, synth, SELECT_INLIERS, SAMPLE_BASIC
+    ctx = Context(local_rank)
+    q = synth.make_query(args.matches, args.inlier_frac, seed=2)
+    ctx.set_query(q["kx"], q["ky"], q["X"], q["Y"], q["Z"], q["width"], q["height"], 0.0)
+    H = args.hyps
+    key_t = torch.zeros(1, dtype=torch.int64, device=f"cuda:{local_rank}") if world > 1 else None
+
+    def step(i):
+        # hypothesis ids are global: rank r owns [ (i*world + r) * H, +H )
+        ctx.sample(SAMPLE_BASIC, 1002, 0, ((i * world + rank) * H) % (1 << 31), H, export=False)
+        r = ctx.ransac_run(SELECT_INLIERS, 0.5, early_exit=False)
+        if world > 1:
+            gh = (i * world + rank) * H + r["best_hyp"]
+            key_t[0] = (int(r["inliers"]) << 32) | (0xFFFFFFFF - (gh & 0xFFFFFFFF))
+            dist.all_reduce(key_t, op=dist.ReduceOp.MAX)
+        return r
+
+    def sync():
+        ctx.synchronize()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    sync()
+    t0 = time.perf_counter()
+    tim = dict(solve_ms=0.0, score_ms=0.0, select_ms=0.0, total_ms=0.0)
+    poses = 0
+    last = None
+    for i in range(args.steps):
+        last = step(args.warmup + i)
+        poses += last["poses_scored"]
+        for k, v in ctx.last_timing().items():
+            tim[k] += v
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        total_hyps = H * args.steps * world
+        info = ctx.device_info()
+        # dominant kernel of the step and its roofline (HIP-event times from the library's stream)
+        solve_s, score_s = tim["solve_ms"] / 1e3, tim["score_ms"] / 1e3
+        pairs = poses * args.matches
+        score_tflops = pairs * SCORE_FLOP_PER_PAIR / score_s / 1e12 if score_s > 0 else 0.0
+        roofline = {"kernel": "k_score", "bound": "valu_fp64", "achieved": round(score_tflops, 3),
+                    "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(score_tflops / FP64_VECTOR_PEAK_TFLOPS, 4),
+                    "traffic": None,
+                    "kernel_ms": {k: round(v / args.steps, 3) for k, v in tim.items()},
+                    "poses_per_hypothesis": round(poses / (H * args.steps), 3),
+                    "dominant": "solve" if solve_s > score_s else "score"}
+        out = {"metric": "RANSAC hypotheses/sec (P4Pf solve+score)", "value": round(total_hyps / dt, 1), "unit": "hypotheses/s",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+               "config": {"workload": "BASELINE configs[1]: P4Pf RANSAC, single query, %d matches, %d%% inliers, %d hypotheses per GPU per step"
+                          % (args.matches, round(args.inlier_frac * 100), H),
+                          "select": "inlier count", "parallelism": "hypothesis range sharded over %d GPU(s)" % world,
+                          "device": info["name"], "best_inliers": int(last["inliers"])},
+               "roofline": roofline}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(q, args)
+        print(json.dumps(out))
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+    return 0
+
+
+def cpu_baseline(q, args):
+    """The CPU oracle (a port of the reference's algorithm; the reference itself needs Eigen,
+    FLANN and OpenCV, which are not installed) on a bounded sample of the same workload."""
+    import oracle_lib as O
+    cores = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16")), 16)
+    n = len(q["kx"])
+    probe = np.array([O.sample_basic(1002, 0, h, 4, n)[0] for h in range(256)], np.uint32)
+    t0 = time.perf_counter()
+    O.ransac_fixed_budget(q["kx"], q["ky"], q["X"], q["Y"], q["Z"], q["width"], q["height"], 0.0, probe, threads=cores)
+    per = (time.perf_counter() - t0) / 256
+    count = args.cpu_hyps or int(min(max(12.0 / max(per, 1e-7), 512), 200000))
+    samples = np.array([O.sample_basic(1002, 0, h, 4, n)[0] for h in range(count)], np.uint32)
+    t0 = time.perf_counter()
+    O.ransac_fixed_budget(q["kx"], q["ky"], q["X"], q["Y"], q["Z"], q["width"], q["height"], 0.0, samples, threads=cores)
+    dt = time.perf_counter() - t0
+    return {"value": round(count / dt, 1), "unit": "hypotheses/s", "cores": cores, "kind": "port",
+            "sample": "%d hypotheses of the same query (same sampler stream), oracle/pose_oracle.c with OpenMP over hypotheses, %.1f s"
+                      % (count, dt)}
+
+
+if __name__ == "__main__":
+    sys.exit(main())

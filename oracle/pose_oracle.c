@@ -471,3 +471,58 @@ int orc_ransac(const orc_query *q, const orc_ransac_params *p, const uint32_t *s
     free(mask);
     return 0;
 }
+
+uint64_t orc_ransac_fixed_budget(const orc_query *q, double eps, const uint32_t *samples, unsigned nsamples,
+                                 int threads, uint64_t *poses_scored)
+{
+    const int p4pfmode = q->focal == 0.0;
+    const int maxsol = p4pfmode ? 10 : 4;
+    const double hw = (double)q->width / 2.0, hh = (double)q->height / 2.0;
+    uint64_t best = 0, scored = 0;
+#ifdef _OPENMP
+#pragma omp parallel for num_threads(threads) schedule(dynamic, 16) reduction(max : best) reduction(+ : scored)
+#endif
+    for (long step = 0; step < (long)nsamples; ++step) {
+        const uint32_t *s = samples + 4 * (size_t)step;
+        int nsol = 0;
+        double fs[10], Cs[30], Rcs[90];
+        if (p4pfmode) {
+            double m2d[8], M3D[12], f[10], R[90], t[30];
+            for (int i = 0; i < 4; ++i) {
+                m2d[2 * i] = -(q->kx[s[i]] - hw); m2d[2 * i + 1] = -(q->ky[s[i]] - hh);
+                M3D[3 * i] = q->X[s[i]]; M3D[3 * i + 1] = q->Y[s[i]]; M3D[3 * i + 2] = q->Z[s[i]];
+            }
+            nsol = orc_p4pf(m2d, M3D, f, R, t);
+            if (nsol < 0) nsol = 0;
+            for (int k = 0; k < nsol; ++k) {
+                fs[k] = f[k];
+                for (int r = 0; r < 3; ++r) {
+                    Cs[3 * k + r] = -(R[9 * k + r] * t[3 * k] + R[9 * k + 3 + r] * t[3 * k + 1] + R[9 * k + 6 + r] * t[3 * k + 2]);
+                    for (int c = 0; c < 3; ++c) Rcs[9 * k + 3 * r + c] = R[9 * k + 3 * c + r];
+                }
+            }
+        } else {
+            double fc[9], pc[9], sol[48];
+            for (int i = 0; i < 3; ++i) {
+                double v[3] = {-(q->kx[s[i]] - hw), -(q->ky[s[i]] - hh), q->focal};
+                double nv = v_norm(v);
+                for (int k = 0; k < 3; ++k) fc[3 * i + k] = v[k] / nv;
+                pc[3 * i] = q->X[s[i]]; pc[3 * i + 1] = q->Y[s[i]]; pc[3 * i + 2] = q->Z[s[i]];
+            }
+            if (orc_p3p_compute_poses(fc, pc, sol) == 0) {
+                nsol = 4;
+                for (int k = 0; k < 4; ++k) { fs[k] = q->focal; memcpy(Cs + 3 * k, sol + 12 * k, 24); memcpy(Rcs + 9 * k, sol + 12 * k + 3, 72); }
+            }
+        }
+        for (int k = 0; k < nsol; ++k) {
+            double P[12];
+            orc_compute_matrices(fs[k], Cs + 3 * k, Rcs + 9 * k, P);
+            const int cnt = orc_score(P, q->n, q->kx, q->ky, q->X, q->Y, q->Z, q->width, q->height, eps, NULL);
+            const uint64_t key = ((uint64_t)(uint32_t)cnt << 32) | (0xFFFFFFFFu - (uint32_t)(step * maxsol + k));
+            if (key > best) best = key;
+            ++scored;
+        }
+    }
+    if (poses_scored) *poses_scored = scored;
+    return best;
+}

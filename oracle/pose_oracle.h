@@ -107,6 +107,13 @@ typedef struct {
 int orc_ransac(const orc_query *q, const orc_ransac_params *p, const uint32_t *samples,
                unsigned nsamples, orc_ransac_result *res, uint8_t *best_mask);
 
+/* Fixed-budget throughput form for the CPU baseline: every sample is solved and every
+ * returned pose scored against all correspondences (inlier-count selection, no early exit),
+ * hypotheses spread over `threads` OpenMP threads.  Returns the packed best key
+ * (count << 32 | ~slot) and the number of poses scored. */
+uint64_t orc_ransac_fixed_budget(const orc_query *q, double eps, const uint32_t *samples, unsigned nsamples,
+                                 int threads, uint64_t *poses_scored);
+
 #ifdef __cplusplus
 }
 #endif

@@ -55,6 +55,8 @@ def load():
     lib.orc_sample_advanced.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_int, C.c_uint32, _up, _up, _up, _up,
                                         C.POINTER(C.c_int)]
     lib.orc_ransac.argtypes = [C.POINTER(OrcQuery), C.POINTER(OrcParams), _up, C.c_uint, C.POINTER(OrcResult), _bp]
+    lib.orc_ransac_fixed_budget.argtypes = [C.POINTER(OrcQuery), C.c_double, _up, C.c_uint, C.c_int, C.POINTER(C.c_uint64)]
+    lib.orc_ransac_fixed_budget.restype = C.c_uint64
     return lib
 
 
@@ -162,3 +164,12 @@ def ransac(kx, ky, X, Y, Z, width, height, focal, samples, select_coverage=True,
     if want_mask:
         out["mask"] = mask
     return out
+
+
+def ransac_fixed_budget(kx, ky, X, Y, Z, width, height, focal, samples, eps=0.5, threads=1):
+    """Returns (best_count, best_slot, poses_scored) of the fixed-budget inlier-count run."""
+    q = OrcQuery(len(kx), _p(kx, _fp), _p(ky, _fp), _p(X, _fp), _p(Y, _fp), _p(Z, _fp), width, height, float(focal))
+    s = np.ascontiguousarray(samples, dtype=np.uint32)
+    scored = C.c_uint64(0)
+    key = lib().orc_ransac_fixed_budget(C.byref(q), eps, _p(s, _up), len(s), int(threads), C.byref(scored))
+    return int(key >> 32), int(0xFFFFFFFF - (key & 0xFFFFFFFF)), scored.value

@@ -104,32 +104,41 @@ def test_p4pf_reference_known_answer(ctx):
 
 
 def p4pf_gate(m, M):
-    """Conditioning gate: fp64 and long-double oracle agree on the solution count and to 1e-10."""
+    """Conditioning gate.  The reference algorithm (78x78 LU + eigenvectors) carries its own
+    rounding error: e_ref = |fp64 oracle - long-double oracle|.  Returns the long-double
+    solution and e_ref, or None when the two oracles disagree on the solution count."""
     n, f, R, t = O.p4pf(m, M)
     n2, f2, R2, t2 = O.p4pf(m, M, long_double=True)
     if n != n2:
         return None
-    if n > 0 and max(relerr(f, f2), relerr(R, R2, 1e-3), relerr(t, t2, 1e-3)) > 1e-10:
-        return None
-    return n, f, R, t
+    e_ref = max(relerr(f, f2), relerr(R, R2, 1e-3), relerr(t, t2, 1e-3)) if n > 0 else 0.0
+    return n, f2, R2, t2, e_ref
+
+
+def p4pf_agrees(nsol, f, R, t, g):
+    """Device result within 1e-8 relative, or within the reference's own rounding uncertainty."""
+    n, f0, R0, t0, e_ref = g
+    if nsol != n:
+        return False
+    if n <= 0:
+        return True
+    e = max(relerr(f[:n], f0), relerr(R[:n], R0, 1e-3), relerr(t[:n], t0, 1e-3))
+    return e < max(RTOL, 20 * e_ref)
 
 
 def test_p4pf_batch_random(ctx):
     m, M = synth.random_p4pf_problems(600, 5)
     nsol, f, R, t = ctx.p4pf_batch(m, M)
-    gated = agree = 0
+    gated = agree = tight = 0
     for i in range(600):
         g = p4pf_gate(m[i], M[i])
         if g is None:
             continue
         gated += 1
-        n, f0, R0, t0 = g
-        if nsol[i] != n:
-            continue
-        if n <= 0 or max(relerr(f[i, :n], f0), relerr(R[i, :n], R0, 1e-3), relerr(t[i, :n], t0, 1e-3)) < RTOL:
-            agree += 1
-    assert gated >= 500
-    assert agree >= gated - 2, (agree, gated)
+        agree += p4pf_agrees(nsol[i], f[i], R[i], t[i], g)
+        tight += g[4] < 1e-9
+    assert gated >= 590 and tight >= 300
+    assert agree >= gated - 3, (agree, gated)
 
 
 def test_p4pf_lapack_fixture(ctx):
@@ -332,8 +341,9 @@ def test_query_processor_basic_process(ctx):
     q = Query(d["kx"], d["ky"], d["X"], d["Y"], d["Z"], d["width"], d["height"], 0.0)
     qp = QueryProcessorBasic(ctx, seed=5)
     assert qp.Process(q) is True
-    assert np.linalg.norm(q.camera_position() - d["C_true"]) < 0.5
-    assert abs(q.focal_length() - d["f_true"]) / d["f_true"] < 0.02
+    # the loop stops at the first kept pose with >= 12 inliers (basic.cpp:132-133): a rough pose
+    assert np.linalg.norm(q.camera_position() - d["C_true"]) < 3.0
+    assert abs(q.focal_length() - d["f_true"]) / d["f_true"] < 0.05
     assert q.fitted_mask.sum() >= 12 and qp.steps < 10000
     # the same samples through the oracle give the same pose
     o = O.ransac(d["kx"], d["ky"], d["X"], d["Y"], d["Z"], d["width"], d["height"], 0.0, qp.samples, select_coverage=True)
