@@ -3,6 +3,8 @@
 #include "dev_math.h"
 #include "p3p_dev.h"
 #include "p4pf_dev.h"
+#include "wave_ops.h"
+#include "p4pf_elim_gen.h"
 
 namespace pose_amd {
 
@@ -214,6 +216,108 @@ __global__ void k_solve_p4pf_template(query_dev q, uint32_t hyp_count, const uin
             double f, R[9], t[3];
             p4pf_pose_from_root(pb, roots[s], f, R, t);
             store_p4pf_solution(proj, pose, h * P4PF_MAXSOL + s, f, R, t);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// P4Pf, stage A+B: template coefficients and the cooperative elimination.
+// One wave per block.  Phase A: lanes 0..31 each prepare one hypothesis (gather the four
+// correspondences, normalise, 42 coefficients -> LDS).  Phase B: the whole wave eliminates
+// the 32 systems one after the other (p4pf_elim_wave) and writes rows 5..9 of each action
+// matrix (50 doubles) plus a status word.  Inputs come either from the resident query +
+// sample tuples or, for the batch entry point, from explicit m2d / M3D arrays.
+// ------------------------------------------------------------------------------------------
+constexpr int ELIM_BATCH = 32;
+
+__device__ __forceinline__ void p4pf_fetch(const query_dev &q, const uint32_t *__restrict__ samples, const double *__restrict__ m2d_in,
+                                           const double *__restrict__ M3D_in, size_t h, double m2d[8], double M3D[12])
+{
+    if (m2d_in) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) m2d[i] = m2d_in[8 * h + i];
+#pragma unroll
+        for (int i = 0; i < 12; ++i) M3D[i] = M3D_in[12 * h + i];
+    } else {
+        gather_p4pf(q, reinterpret_cast<const uint4 *>(samples)[h], m2d, M3D);
+    }
+}
+
+__global__ __launch_bounds__(64) void k_p4pf_elim(query_dev q, uint32_t hyp_count, const uint32_t *__restrict__ samples,
+                                                  const double *__restrict__ m2d_in, const double *__restrict__ M3D_in,
+                                                  double *__restrict__ Arows, int *__restrict__ status)
+{
+    __shared__ double cf[ELIM_BATCH][43];
+    __shared__ int st_s[ELIM_BATCH];
+    const int lane = threadIdx.x;
+    const uint32_t nbatch = (hyp_count + ELIM_BATCH - 1) / ELIM_BATCH;
+    for (uint32_t b = blockIdx.x; b < nbatch; b += gridDim.x) {
+        if (lane < ELIM_BATCH) {
+            const size_t h = (size_t)b * ELIM_BATCH + lane;
+            int st = -1;
+            if (h < hyp_count) {
+                double m2d[8], M3D[12], k[42];
+                p4pf_fetch(q, samples, m2d_in, M3D_in, h, m2d, M3D);
+                p4pf_problem pb;
+                st = p4pf_normalise(m2d, M3D, pb);
+                p4pf_coefs(pb.gl[0], pb.gl[1], pb.gl[2], pb.gl[3], pb.gl[4], pb.gl[5], pb.m2D[0], pb.m2D[1], pb.m2D[2], pb.m2D[3],
+                           pb.m2D[4], pb.m2D[5], pb.m2D[6], pb.m2D[7], k);
+#pragma unroll
+                for (int g = 0; g < 42; ++g) cf[lane][g] = k[g];
+                cf[lane][42] = 0.0;
+            }
+            st_s[lane] = st;
+        }
+        __syncthreads();
+        for (int i = 0; i < ELIM_BATCH; ++i) {
+            const size_t h = (size_t)b * ELIM_BATCH + i;
+            if (h >= hyp_count) break;
+            const int st = __builtin_amdgcn_readfirstlane(st_s[i]);
+            if (st != 0) { if (lane == 0) status[h] = -1; continue; }
+            double k[42];
+#pragma unroll
+            for (int g = 0; g < 42; ++g) k[g] = wave_uniform(cf[i][g]);
+            const int rc = p4pf_elim_wave(k, &cf[i][0], Arows + h * 50);
+            if (lane == 0) status[h] = rc;
+        }
+        __syncthreads();
+    }
+}
+
+// P4Pf, stage C: one hypothesis per lane.  Action matrix -> accepted roots -> (f, R, t).
+// With proj != null the solutions go to the pose slots of the RANSAC pipeline, otherwise to
+// the flat arrays of the batch entry point.
+__global__ void k_p4pf_finish(query_dev q, uint32_t hyp_count, const uint32_t *__restrict__ samples, const double *__restrict__ m2d_in,
+                              const double *__restrict__ M3D_in, const double *__restrict__ Arows, const int *__restrict__ status,
+                              double *__restrict__ proj, double *__restrict__ pose, int *__restrict__ nsol, double *__restrict__ fo,
+                              double *__restrict__ Ro, double *__restrict__ to)
+{
+    const size_t h = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (h >= hyp_count) return;
+    int n = status[h];
+    p4pf_problem pb;
+    p4pf_root roots[10];
+    if (n == 0) {
+        double m2d[8], M3D[12];
+        p4pf_fetch(q, samples, m2d_in, M3D_in, h, m2d, M3D);
+        p4pf_normalise(m2d, M3D, pb);
+        double A[100];
+#pragma unroll
+        for (int i = 0; i < 50; ++i) A[i] = 0.0;
+        A[0 * 10 + 1] = 1; A[1 * 10 + 5] = 1; A[2 * 10 + 6] = 1; A[3 * 10 + 7] = 1; A[4 * 10 + 8] = 1;
+        for (int i = 0; i < 50; ++i) A[50 + i] = Arows[h * 50 + i];
+        n = p4pf_roots_from_action(A, roots);
+    }
+    nsol[h] = n;
+    for (int s = 0; s < n; ++s) {
+        double f, R[9], t[3];
+        p4pf_pose_from_root(pb, roots[s], f, R, t);
+        if (proj) {
+            store_p4pf_solution(proj, pose, h * P4PF_MAXSOL + s, f, R, t);
+        } else {
+            fo[10 * h + s] = f;
+            for (int r = 0; r < 9; ++r) Ro[90 * h + 9 * s + r] = R[r];
+            for (int r = 0; r < 3; ++r) to[30 * h + 3 * s + r] = t[r];
         }
     }
 }

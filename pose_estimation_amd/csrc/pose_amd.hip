@@ -36,7 +36,7 @@ struct pose_amd_ctx {
     // hypotheses
     uint32_t hyp_count = 0;
     int solver = POSE_AMD_SOLVER_P4PF;
-    dev_buf samples, sample_status, proj, pose, nsol, counts, sel, ws, bitmaps, areas, maskw;
+    dev_buf samples, sample_status, proj, pose, nsol, counts, sel, ws, bitmaps, areas, maskw, arows, pstatus;
     // scratch for batch entry points
     dev_buf in0, in1, in2, out0, out1, out2, out3;
     // last run
@@ -112,6 +112,25 @@ static int ensure_ws(pose_amd_ctx *ctx, size_t problems, int &blocks)
     return ensure(ctx, ctx->ws, lanes * 78 * 88 * sizeof(double));
 }
 
+// P4Pf minimal solves for `count` hypotheses: cooperative elimination, then per-lane eigen
+// step and pose recovery.  Exactly one of (samples) / (m2d, M3D) is given.
+static int launch_p4pf(pose_amd_ctx *ctx, uint32_t count, const uint32_t *samples, const double *m2d, const double *M3D,
+                       double *proj, double *pose, int *nsol, double *fo, double *Ro, double *to)
+{
+    int rc;
+    if ((rc = ensure(ctx, ctx->arows, (size_t)count * 400)) || (rc = ensure(ctx, ctx->pstatus, (size_t)count * 4))) return rc;
+    const query_dev q = make_query(ctx);
+    const int nbatch = cdiv(count, ELIM_BATCH);
+    const int max_blocks = (ctx->cus ? ctx->cus : 256) * 8;
+    hipLaunchKernelGGL(k_p4pf_elim, dim3(std::min(nbatch, max_blocks)), dim3(64), 0, ctx->stream, q, count, samples, m2d, M3D,
+                       (double *)ctx->arows.p, (int *)ctx->pstatus.p);
+    HIPCHK(ctx, hipGetLastError());
+    hipLaunchKernelGGL(k_p4pf_finish, dim3(cdiv(count, 64)), dim3(64), 0, ctx->stream, q, count, samples, m2d, M3D,
+                       (const double *)ctx->arows.p, (const int *)ctx->pstatus.p, proj, pose, nsol, fo, Ro, to);
+    HIPCHK(ctx, hipGetLastError());
+    return POSE_AMD_OK;
+}
+
 extern "C" {
 
 int pose_amd_create(int device, pose_amd_ctx **out)
@@ -161,7 +180,7 @@ void pose_amd_destroy(pose_amd_ctx *c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     dev_buf *bufs[] = {&c->kx, &c->ky, &c->X, &c->Y, &c->Z, &c->lindex, &c->cam_off, &c->cam_ids, &c->gain, &c->samples,
                        &c->sample_status, &c->proj, &c->pose, &c->nsol, &c->counts, &c->sel, &c->ws, &c->bitmaps, &c->areas,
-                       &c->maskw, &c->in0, &c->in1, &c->in2, &c->out0, &c->out1, &c->out2, &c->out3};
+                       &c->maskw, &c->arows, &c->pstatus, &c->in0, &c->in1, &c->in2, &c->out0, &c->out1, &c->out2, &c->out3};
     for (dev_buf *b : bufs) if (b->p) (void)hipFree(b->p);
     for (int i = 0; i < 4; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -226,21 +245,19 @@ int pose_amd_p4pf_batch(pose_amd_ctx *ctx, int count, const double *m2d, const d
     if (!ctx || count < 0 || (count && (!m2d || !M3D || !nsol || !f || !R || !t))) return fail(ctx, POSE_AMD_EINVAL, "p4pf_batch: bad argument");
     if (count == 0) return POSE_AMD_OK;
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    int rc, blocks;
+    int rc;
     if ((rc = upload(ctx, ctx->in0, m2d, (size_t)count * 64))) return rc;
     if ((rc = upload(ctx, ctx->in1, M3D, (size_t)count * 96))) return rc;
     if ((rc = ensure(ctx, ctx->out0, (size_t)count * 4))) return rc;
     if ((rc = ensure(ctx, ctx->out1, (size_t)count * 80))) return rc;
     if ((rc = ensure(ctx, ctx->out2, (size_t)count * 720))) return rc;
     if ((rc = ensure(ctx, ctx->out3, (size_t)count * 240))) return rc;
-    if ((rc = ensure_ws(ctx, (size_t)count, blocks))) return rc;
     HIPCHK(ctx, hipMemsetAsync(ctx->out1.p, 0, (size_t)count * 80, ctx->stream));
     HIPCHK(ctx, hipMemsetAsync(ctx->out2.p, 0, (size_t)count * 720, ctx->stream));
     HIPCHK(ctx, hipMemsetAsync(ctx->out3.p, 0, (size_t)count * 240, ctx->stream));
-    hipLaunchKernelGGL(k_p4pf_batch, dim3(blocks), dim3(64), 0, ctx->stream, count, (const double *)ctx->in0.p,
-                       (const double *)ctx->in1.p, (double *)ctx->ws.p, (int *)ctx->out0.p, (double *)ctx->out1.p,
-                       (double *)ctx->out2.p, (double *)ctx->out3.p);
-    HIPCHK(ctx, hipGetLastError());
+    if ((rc = launch_p4pf(ctx, (uint32_t)count, nullptr, (const double *)ctx->in0.p, (const double *)ctx->in1.p, nullptr, nullptr,
+                          (int *)ctx->out0.p, (double *)ctx->out1.p, (double *)ctx->out2.p, (double *)ctx->out3.p)))
+        return rc;
     if ((rc = download(ctx, nsol, ctx->out0.p, (size_t)count * 4))) return rc;
     if ((rc = download(ctx, f, ctx->out1.p, (size_t)count * 80))) return rc;
     if ((rc = download(ctx, R, ctx->out2.p, (size_t)count * 720))) return rc;
@@ -460,10 +477,9 @@ static int solve_and_score(pose_amd_ctx *ctx, uint32_t h0, uint32_t hc, int maxs
     int rc;
     HIPCHK(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
     if (ctx->solver == POSE_AMD_SOLVER_P4PF) {
-        int blocks;
-        if ((rc = ensure_ws(ctx, hc, blocks))) return rc;
-        hipLaunchKernelGGL(k_solve_p4pf_template, dim3(blocks), dim3(64), 0, ctx->stream, q, hc, smp, (double *)ctx->ws.p,
-                           (double *)ctx->proj.p, (double *)ctx->pose.p, (int *)ctx->nsol.p);
+        if ((rc = launch_p4pf(ctx, hc, smp, nullptr, nullptr, (double *)ctx->proj.p, (double *)ctx->pose.p, (int *)ctx->nsol.p,
+                              nullptr, nullptr, nullptr)))
+            return rc;
     } else {
         hipLaunchKernelGGL(k_solve_p3p, dim3(cdiv(hc, 64)), dim3(64), 0, ctx->stream, q, hc, smp, (double *)ctx->proj.p,
                            (double *)ctx->pose.p, (int *)ctx->nsol.p);

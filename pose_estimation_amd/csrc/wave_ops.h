@@ -1,0 +1,45 @@
+// Wave64 cross-lane helpers used by the cooperative elimination kernel (gfx950).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace pose_amd {
+
+// Value of `v` in lane `src` as a wave-uniform double (two v_readlane_b32 -> scalar registers).
+__device__ __forceinline__ double wave_bcast(double v, int src)
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+    return __hiloint2double(hi, lo);
+}
+// Same with a run-time (but wave-uniform) source lane.
+__device__ __forceinline__ double wave_bcast_dyn(double v, int src) { return wave_bcast(v, src); }
+
+// Makes a value that every lane holds identically known-uniform to the compiler.
+__device__ __forceinline__ double wave_uniform(double v)
+{
+    const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v));
+    const int hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+
+// Lane holding the largest |x| among lanes with cand == true (lowest such lane on ties of the
+// 32-bit key).  Magnitudes are compared after rounding to float32, which keeps the order up to
+// 2^-24 relative: enough for pivot selection.  Candidates always beat non-candidates; if no
+// lane is a candidate the result is lane 0.
+__device__ __forceinline__ int wave_argmax_abs(double x, bool cand)
+{
+    unsigned key = cand ? (__float_as_uint((float)fabs(x)) + 1u) : 0u;
+    unsigned m = key;
+    // butterfly inside each row of 16 lanes with DPP: xor 1, xor 2, half-mirror, mirror
+    m = max(m, (unsigned)__builtin_amdgcn_update_dpp(0, (int)m, 0xB1, 0xf, 0xf, true));
+    m = max(m, (unsigned)__builtin_amdgcn_update_dpp(0, (int)m, 0x4E, 0xf, 0xf, true));
+    m = max(m, (unsigned)__builtin_amdgcn_update_dpp(0, (int)m, 0x141, 0xf, 0xf, true));
+    m = max(m, (unsigned)__builtin_amdgcn_update_dpp(0, (int)m, 0x140, 0xf, 0xf, true));
+    const unsigned a = (unsigned)__builtin_amdgcn_readlane((int)m, 0), b = (unsigned)__builtin_amdgcn_readlane((int)m, 16),
+                   c = (unsigned)__builtin_amdgcn_readlane((int)m, 32), d = (unsigned)__builtin_amdgcn_readlane((int)m, 48);
+    const unsigned best = max(max(a, b), max(c, d));
+    const unsigned long long who = __ballot(key == best);
+    return (int)__builtin_ctzll(who | (1ull << 63));
+}
+
+} // namespace pose_amd
