@@ -3,6 +3,7 @@
 #include "dev_math.h"
 #include "p3p_dev.h"
 #include "p4pf_dev.h"
+#include "p4pf_eig_dev.h"
 #include "wave_ops.h"
 #include "p4pf_elim_gen.h"
 
@@ -187,39 +188,6 @@ __device__ __forceinline__ void gather_p4pf(const query_dev &q, const uint4 s, d
     }
 }
 
-// P4Pf branch (query_processor_basic.cpp:154-226), template solver: grid-stride over
-// hypotheses, each lane reusing its own 78x88 slice of the workspace.
-__global__ void k_solve_p4pf_template(query_dev q, uint32_t hyp_count, const uint32_t *__restrict__ samples,
-                                      double *__restrict__ ws, double *__restrict__ proj, double *__restrict__ pose,
-                                      int *__restrict__ nsol)
-{
-    const size_t lanes = (size_t)gridDim.x * blockDim.x, lane = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    for (size_t h0 = 0; h0 < hyp_count; h0 += lanes) {
-        const size_t h = h0 + lane;
-        const bool act = h < hyp_count;
-        double m2d[8], M3D[12];
-        if (act) gather_p4pf(q, reinterpret_cast<const uint4 *>(samples)[h], m2d, M3D);
-        else { for (int i = 0; i < 8; ++i) m2d[i] = i + 1.0; for (int i = 0; i < 12; ++i) M3D[i] = (i * 7 % 5) + 0.25 * i; }
-        p4pf_problem pb;
-        int n = p4pf_normalise(m2d, M3D, pb);
-        p4pf_root roots[10];
-        if (n == 0) {
-            double k[42], A[100];
-            p4pf_coefs(pb.gl[0], pb.gl[1], pb.gl[2], pb.gl[3], pb.gl[4], pb.gl[5], pb.m2D[0], pb.m2D[1], pb.m2D[2], pb.m2D[3],
-                       pb.m2D[4], pb.m2D[5], pb.m2D[6], pb.m2D[7], k);
-            n = p4pf_template_solve(k, ws + lane, lanes, A);
-            if (n == 0) n = p4pf_roots_from_action(A, roots);
-        }
-        if (!act) continue;
-        nsol[h] = n;
-        for (int s = 0; s < n; ++s) {
-            double f, R[9], t[3];
-            p4pf_pose_from_root(pb, roots[s], f, R, t);
-            store_p4pf_solution(proj, pose, h * P4PF_MAXSOL + s, f, R, t);
-        }
-    }
-}
-
 // ------------------------------------------------------------------------------------------
 // P4Pf, stage A+B: template coefficients and the cooperative elimination.
 // One wave per block.  Phase A: lanes 0..31 each prepare one hypothesis (gather the four
@@ -301,12 +269,10 @@ __global__ void k_p4pf_finish(query_dev q, uint32_t hyp_count, const uint32_t *_
         double m2d[8], M3D[12];
         p4pf_fetch(q, samples, m2d_in, M3D_in, h, m2d, M3D);
         p4pf_normalise(m2d, M3D, pb);
-        double A[100];
+        double a[50];
 #pragma unroll
-        for (int i = 0; i < 50; ++i) A[i] = 0.0;
-        A[0 * 10 + 1] = 1; A[1 * 10 + 5] = 1; A[2 * 10 + 6] = 1; A[3 * 10 + 7] = 1; A[4 * 10 + 8] = 1;
-        for (int i = 0; i < 50; ++i) A[50 + i] = Arows[h * 50 + i];
-        n = p4pf_roots_from_action(A, roots);
+        for (int i = 0; i < 50; ++i) a[i] = Arows[h * 50 + i];
+        n = p4pf_roots_sextic(a, pb, roots);
     }
     nsol[h] = n;
     for (int s = 0; s < n; ++s) {
@@ -350,38 +316,6 @@ __global__ void k_quartic_batch(int count, const double *__restrict__ factors, d
     for (int k = 0; k < 4; ++k) roots[4 * (size_t)i + k] = r[k];
 }
 
-__global__ void k_p4pf_batch(int count, const double *__restrict__ m2d_in, const double *__restrict__ M3D_in, double *__restrict__ ws,
-                             int *__restrict__ nsol, double *__restrict__ fo, double *__restrict__ Ro, double *__restrict__ to)
-{
-    const size_t lanes = (size_t)gridDim.x * blockDim.x, lane = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    for (size_t h0 = 0; h0 < (size_t)count; h0 += lanes) {
-        const size_t h = h0 + lane;
-        const bool act = h < (size_t)count;
-        double m2d[8], M3D[12];
-        for (int i = 0; i < 8; ++i) m2d[i] = act ? m2d_in[8 * h + i] : i + 1.0;
-        for (int i = 0; i < 12; ++i) M3D[i] = act ? M3D_in[12 * h + i] : (i * 7 % 5) + 0.25 * i;
-        p4pf_problem pb;
-        int n = p4pf_normalise(m2d, M3D, pb);
-        p4pf_root roots[10];
-        if (n == 0) {
-            double k[42], A[100];
-            p4pf_coefs(pb.gl[0], pb.gl[1], pb.gl[2], pb.gl[3], pb.gl[4], pb.gl[5], pb.m2D[0], pb.m2D[1], pb.m2D[2],
-                       pb.m2D[3], pb.m2D[4], pb.m2D[5], pb.m2D[6], pb.m2D[7], k);
-            n = p4pf_template_solve(k, ws + lane, lanes, A);
-            if (n == 0) n = p4pf_roots_from_action(A, roots);
-        }
-        if (!act) continue;
-        nsol[h] = n;
-        for (int s = 0; s < n; ++s) {
-            double f, R[9], t[3];
-            p4pf_pose_from_root(pb, roots[s], f, R, t);
-            fo[10 * h + s] = f;
-            for (int r = 0; r < 9; ++r) Ro[90 * h + 9 * s + r] = R[r];
-            for (int r = 0; r < 3; ++r) to[30 * h + 3 * s + r] = t[r];
-        }
-    }
-}
-
 __global__ void k_compute_matrices(int count, const double *__restrict__ focal, const double *__restrict__ C, const double *__restrict__ Rc,
                                    double *__restrict__ P)
 {
@@ -407,7 +341,14 @@ __global__ void k_compute_matrices(int count, const double *__restrict__ focal, 
 // within rounding of the threshold.  Per-wave inlier counts come from ballot + popcount.
 // ------------------------------------------------------------------------------------------
 constexpr int SCORE_THREADS = 256;
-constexpr int SCORE_SPB = 32;        // pose slots per block
+constexpr int SCORE_SPB = 256;       // pose slots per block
+
+__device__ __forceinline__ void load_pose_uniform(const double *__restrict__ proj, int slot, double (&P)[12])
+{
+    const double *__restrict__ p = proj + (size_t)slot * 12;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) P[i] = p[i];
+}
 
 template <int KC, bool MASK>
 __global__ __launch_bounds__(SCORE_THREADS) void k_score(query_dev q, int nslots, const double *__restrict__ proj,
@@ -415,62 +356,81 @@ __global__ __launch_bounds__(SCORE_THREADS) void k_score(query_dev q, int nslots
                                                          int *__restrict__ counts, unsigned long long *__restrict__ mask,
                                                          int words_per_pose)
 {
-    __shared__ int s_cnt[SCORE_THREADS / 64][SCORE_SPB];
+    __shared__ int s_cnt[SCORE_SPB];
+    __shared__ int s_list[SCORE_SPB];
+    __shared__ int s_wave_n[SCORE_THREADS / 64];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int slot0 = blockIdx.x * SCORE_SPB;
-    if (tid < SCORE_SPB * (SCORE_THREADS / 64)) (&s_cnt[0][0])[tid] = 0;
-    __syncthreads();
-    const double hw = (double)q.width / 2.0, hh = (double)q.height / 2.0;
-    const int tile_sz = SCORE_THREADS * KC;
-    for (int base = 0; base < q.n; base += tile_sz) {
-        double u[KC], v[KC], X[KC], Y[KC], Z[KC];
+    // compact list of the block's valid slots (a hypothesis with nsol solutions owns slots 0..nsol-1)
+    {
+        const int slot = slot0 + tid;
+        bool valid = slot < nslots;
+        if (valid && nsol) valid = (slot % maxsol) < nsol[slot / maxsol];
+        s_cnt[tid] = 0;
+        const unsigned long long b = __ballot(valid);
+        if (lane == 0) s_wave_n[wave] = __popcll(b);
+        __syncthreads();
+        int base = 0;
 #pragma unroll
-        for (int k = 0; k < KC; ++k) {
-            const int idx = base + k * SCORE_THREADS + tid;
-            if (idx < q.n) {
-                u[k] = -((double)q.kx[idx] - hw); v[k] = -((double)q.ky[idx] - hh);
-                X[k] = (double)q.X[idx]; Y[k] = (double)q.Y[idx]; Z[k] = (double)q.Z[idx];
-            } else {
-                u[k] = __longlong_as_double(0x7ff8000000000000ll); v[k] = 0; X[k] = 0; Y[k] = 0; Z[k] = 0;   // never an inlier
-            }
-        }
-        for (int s = 0; s < SCORE_SPB; ++s) {
-            const int slot = slot0 + s;
-            if (slot >= nslots) break;
-            if (nsol) { if ((slot % maxsol) >= nsol[slot / maxsol]) continue; }
-            const double *__restrict__ P = proj + (size_t)slot * 12;
-            const double p0 = P[0], p1 = P[1], p2 = P[2], p3 = P[3], p4 = P[4], p5 = P[5], p6 = P[6], p7 = P[7], p8 = P[8],
-                         p9 = P[9], p10 = P[10], p11 = P[11];
-            int cnt = 0;
+        for (int w = 0; w < SCORE_THREADS / 64; ++w) if (w < wave) base += s_wave_n[w];
+        if (valid) s_list[base + __popcll(b & ((1ull << lane) - 1ull))] = slot;
+        __syncthreads();
+    }
+    int nvalid = 0;
+#pragma unroll
+    for (int w = 0; w < SCORE_THREADS / 64; ++w) nvalid += s_wave_n[w];
+    nvalid = __builtin_amdgcn_readfirstlane(nvalid);
+    if (nvalid > 0) {
+        const double hw = (double)q.width / 2.0, hh = (double)q.height / 2.0;
+        const int tile_sz = SCORE_THREADS * KC;
+        for (int base = 0; base < q.n; base += tile_sz) {
+            double u[KC], v[KC], X[KC], Y[KC], Z[KC];
 #pragma unroll
             for (int k = 0; k < KC; ++k) {
-                const double px = fma(p0, X[k], fma(p1, Y[k], fma(p2, Z[k], p3)));
-                const double py = fma(p4, X[k], fma(p5, Y[k], fma(p6, Z[k], p7)));
-                const double pz = fma(p8, X[k], fma(p9, Y[k], fma(p10, Z[k], p11)));
-                const double rx = fma(u[k], pz, -px), ry = fma(v[k], pz, -py);
-                const double d2 = fma(ry, ry, rx * rx);
-                const double te = eps * pz;
-                const bool in = d2 < te * te;
-                const unsigned long long b = __ballot(in);
-                cnt += __popcll(b);
-                if (MASK) {
-                    const int word = (base + k * SCORE_THREADS + wave * 64) >> 6;
-                    if (lane == 0 && word < words_per_pose) mask[(size_t)slot * words_per_pose + word] = b;
+                const int idx = base + k * SCORE_THREADS + tid;
+                if (idx < q.n) {
+                    u[k] = -((double)q.kx[idx] - hw); v[k] = -((double)q.ky[idx] - hh);
+                    X[k] = (double)q.X[idx]; Y[k] = (double)q.Y[idx]; Z[k] = (double)q.Z[idx];
+                } else {
+                    u[k] = __longlong_as_double(0x7ff8000000000000ll); v[k] = 0; X[k] = 0; Y[k] = 0; Z[k] = 0;   // never an inlier
                 }
             }
-            if (lane == 0) s_cnt[wave][s] += cnt;
+            // the next pose matrix is fetched (scalar loads) while the current one is being scored
+            int slot_n = __builtin_amdgcn_readfirstlane(s_list[0]);
+            double Pn[12];
+            load_pose_uniform(proj, slot_n, Pn);
+            for (int i = 0; i < nvalid; ++i) {
+                const int slot = slot_n;
+                double P[12];
+#pragma unroll
+                for (int j = 0; j < 12; ++j) P[j] = Pn[j];
+                if (i + 1 < nvalid) {
+                    slot_n = __builtin_amdgcn_readfirstlane(s_list[i + 1]);
+                    load_pose_uniform(proj, slot_n, Pn);
+                }
+                int cnt = 0;
+#pragma unroll
+                for (int k = 0; k < KC; ++k) {
+                    const double px = fma(P[0], X[k], fma(P[1], Y[k], fma(P[2], Z[k], P[3])));
+                    const double py = fma(P[4], X[k], fma(P[5], Y[k], fma(P[6], Z[k], P[7])));
+                    const double pz = fma(P[8], X[k], fma(P[9], Y[k], fma(P[10], Z[k], P[11])));
+                    const double rx = fma(u[k], pz, -px), ry = fma(v[k], pz, -py);
+                    const double d2 = fma(ry, ry, rx * rx);
+                    const double te = eps * pz;
+                    const bool in = d2 < te * te;
+                    const unsigned long long b = __ballot(in);
+                    cnt += __popcll(b);
+                    if (MASK) {
+                        const int word = (base + k * SCORE_THREADS + wave * 64) >> 6;
+                        if (lane == 0 && word < words_per_pose) mask[(size_t)slot * words_per_pose + word] = b;
+                    }
+                }
+                if (lane == 0 && cnt) atomicAdd(&s_cnt[slot - slot0], cnt);
+            }
         }
     }
     __syncthreads();
-    if (tid < SCORE_SPB) {
-        const int slot = slot0 + tid;
-        if (slot < nslots) {
-            int c = 0;
-#pragma unroll
-            for (int w = 0; w < SCORE_THREADS / 64; ++w) c += s_cnt[w][tid];
-            counts[slot] = c;
-        }
-    }
+    if (slot0 + tid < nslots) counts[slot0 + tid] = s_cnt[tid];
 }
 
 // ------------------------------------------------------------------------------------------

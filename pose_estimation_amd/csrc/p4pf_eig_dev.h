@@ -1,0 +1,321 @@
+// Per-lane, register-resident replacement for the eigen step of the P4Pf solver
+// (reference P4pf.cpp:1094-1223: 10x10 action matrix -> ComplexEigenSolver -> real roots).
+//
+// Structure used.  Rows 0..4 of the action matrix are shifts (A(0,1)=A(1,5)=A(2,6)=A(3,7)=
+// A(4,8)=1), so an eigenvector v with v0 = 1 has v1 = L, v5 = L^2, v6 = L v2, v7 = L v3,
+// v8 = L v4 and rows 5..9 become a 5x5 polynomial system  P(L) (1, v2, v3, v4, v9)^T = 0 whose
+// determinant is the characteristic polynomial (degree 10).  For the four equations the
+// reference solves, four of the ten eigenvalues are always degenerate: L = 0 twice and the two
+// complex roots of |L d - a|^2 (a, d = first and fourth normalised image points); they have
+// f^2 <= 0 or complex f^2 and never pass the acceptance test (P4pf.cpp:1170-1173).  Dividing them
+// out leaves a sextic; its real roots are isolated by bracketing between the roots of
+// successive derivatives, polished by Newton steps on det P(L) evaluated with a pivoted 5x5
+// elimination (backward stable in the entries of A), and the same elimination yields the
+// eigenvector components zc = v2, zb = v3, f^2 = v4.
+// Known divergence from the reference: a complex-conjugate eigenpair whose f^2 has
+// |imaginary part| < 1e-5 is accepted by the reference (twice, with real parts); it is dropped
+// here.  This needs two real roots about to merge and is rare (see DESIGN.md for rates).
+#pragma once
+#include "p4pf_dev.h"
+
+namespace pose_amd {
+
+#define PA_HD __host__ __device__ __forceinline__
+
+// out += s * a * b   (ascending coefficient arrays)
+template <int NA, int NB>
+PA_HD void poly_mac(double (&out)[NA + NB - 1], const double (&a)[NA], const double (&b)[NB], double s)
+{
+#pragma unroll
+    for (int i = 0; i < NA; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j) out[i + j] = fma(s * a[i], b[j], out[i + j]);
+}
+
+template <int N>
+PA_HD double poly_eval(const double (&c)[N + 1], double x)
+{
+    double v = c[N];
+#pragma unroll
+    for (int i = N - 1; i >= 0; --i) v = fma(v, x, c[i]);
+    return v;
+}
+
+template <int N>
+PA_HD void poly_eval2(const double (&c)[N + 1], double x, double &v, double &dv)
+{
+    v = c[N]; dv = 0.0;
+#pragma unroll
+    for (int i = N - 1; i >= 0; --i) { dv = fma(dv, x, v); v = fma(v, x, c[i]); }
+}
+
+// Root of a degree-N polynomial inside a bracket [a, b] with p(a) p(b) < 0: Newton steps,
+// bisection whenever a step leaves the bracket.
+template <int N>
+PA_HD double poly_refine(const double (&c)[N + 1], double a, double b, double fa)
+{
+    double x = 0.5 * (a + b);
+    for (int it = 0; it < 80; ++it) {
+        double f, df;
+        poly_eval2<N>(c, x, f, df);
+        if (f == 0.0) return x;
+        if ((f < 0.0) == (fa < 0.0)) a = x; else b = x;
+        double xn = x - f / df;
+        if (!(xn > a && xn < b)) xn = 0.5 * (a + b);
+        const double step = fabs(xn - x);
+        x = xn;
+        if (step <= 4e-16 * fmax(1.0, fabs(x)) || b - a <= 4e-16 * fmax(1.0, fabs(x))) break;
+    }
+    return x;
+}
+
+// Real roots of a degree-N polynomial in [lo, hi], ascending.  Roots of even multiplicity are
+// not reported.  r[] entries beyond the returned count are unspecified.
+template <int N>
+struct poly_roots {
+    static PA_HD int find(const double (&c)[N + 1], double lo, double hi, double (&r)[N])
+    {
+        double d[N], crit[N - 1];
+#pragma unroll
+        for (int i = 0; i < N; ++i) d[i] = (i + 1) * c[i + 1];
+        const int ncrit = poly_roots<N - 1>::find(d, lo, hi, crit);
+        int n = 0;
+        double a = lo, fa = poly_eval<N>(c, lo);
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+            const double b = k < ncrit ? crit[k < N - 1 ? k : 0] : hi;
+            const double fb = poly_eval<N>(c, b);
+            double root = 0.0;
+            bool have = false;
+            if (b > a && ((fa < 0.0 && fb > 0.0) || (fa > 0.0 && fb < 0.0))) { root = poly_refine<N>(c, a, b, fa); have = true; }
+            else if (fb == 0.0 && (k >= ncrit) && b > a) { root = b; have = true; }      // root exactly at the upper end
+            else if (fa == 0.0 && k == 0) { root = a; have = true; }                     // root exactly at the lower end
+            if (have) {
+#pragma unroll
+                for (int j = 0; j < N; ++j) if (j == n) r[j] = root;
+                ++n;
+            }
+            a = b; fa = fb;
+        }
+        return n;
+    }
+};
+template <>
+struct poly_roots<1> {
+    static PA_HD int find(const double (&c)[2], double lo, double hi, double (&r)[1])
+    {
+        if (c[1] == 0.0) return 0;
+        const double x = -c[0] / c[1];
+        if (x >= lo && x <= hi) { r[0] = x; return 1; }
+        return 0;
+    }
+};
+template <>
+struct poly_roots<2> {
+    static PA_HD int find(const double (&c)[3], double lo, double hi, double (&r)[2])
+    {
+        if (c[2] == 0.0) {
+            double r1[1];
+            const double c1[2] = {c[0], c[1]};
+            const int n = poly_roots<1>::find(c1, lo, hi, r1);
+            if (n) r[0] = r1[0];
+            return n;
+        }
+        const double disc = c[1] * c[1] - 4.0 * c[2] * c[0];
+        if (!(disc > 0.0)) return 0;
+        const double q = -0.5 * (c[1] + (c[1] >= 0.0 ? 1.0 : -1.0) * sqrt(disc));
+        double x1 = q / c[2], x2 = q != 0.0 ? c[0] / q : x1;
+        if (x1 > x2) { const double t = x1; x1 = x2; x2 = t; }
+        int n = 0;
+        if (x1 >= lo && x1 <= hi) r[n++] = x1;
+        if (x2 >= lo && x2 <= hi) { if (n == 0) r[0] = x2; else r[1] = x2; ++n; }
+        return n;
+    }
+};
+
+// The five polynomial columns of P(L) evaluated at L, as the augmented system [B | -c0]:
+// rows r = 0..4 (action matrix rows 5..9), B columns = coefficients of (v2, v3, v4, v9).
+PA_HD void p4pf_build_system(const double (&a)[50], double L, double (&S)[5][5])
+{
+    const double L2 = L * L;
+#pragma unroll
+    for (int r = 0; r < 5; ++r) {
+        const double *ar = a + 10 * r;
+        S[r][0] = fma(ar[6], L, ar[2]) - (r == 1 ? L2 : 0.0);
+        S[r][1] = fma(ar[7], L, ar[3]) - (r == 2 ? L2 : 0.0);
+        S[r][2] = fma(ar[8], L, ar[4]) - (r == 3 ? L2 : 0.0);
+        S[r][3] = ar[9] - (r == 4 ? L : 0.0);
+        S[r][4] = -(fma(fma(ar[5], L, ar[1]), L, ar[0]) - (r == 0 ? L2 * L : 0.0));
+    }
+}
+
+// Pivoted elimination of the 5x5 augmented system.  Returns det[B | -c0] (= -charpoly(L)) and,
+// from the four pivot rows, y = (v2, v3, v4, v9).
+PA_HD double p4pf_solve_system(double (&S)[5][5], double (&y)[4])
+{
+    double det = 1.0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+#pragma unroll
+        for (int p = k + 1; p < 5; ++p) {
+            if (fabs(S[p][k]) > fabs(S[k][k])) {
+#pragma unroll
+                for (int j = k; j < 5; ++j) { const double t = S[k][j]; S[k][j] = S[p][j]; S[p][j] = t; }
+                det = -det;
+            }
+        }
+        const double pv = S[k][k];
+        det *= pv;
+        const double ip = 1.0 / pv;
+#pragma unroll
+        for (int p = k + 1; p < 5; ++p) {
+            const double m = S[p][k] * ip;
+#pragma unroll
+            for (int j = k + 1; j < 5; ++j) S[p][j] = fma(-m, S[k][j], S[p][j]);
+        }
+    }
+    det *= S[4][4];
+    y[3] = S[3][4] / S[3][3];
+    y[2] = (S[2][4] - S[2][3] * y[3]) / S[2][2];
+    y[1] = (S[1][4] - S[1][2] * y[2] - S[1][3] * y[3]) / S[1][1];
+    y[0] = (S[0][4] - S[0][1] * y[1] - S[0][2] * y[2] - S[0][3] * y[3]) / S[0][0];
+    return det;
+}
+
+// Characteristic polynomial det P(L), ascending coefficients p[0..10], by Laplace expansion
+// over the column pairs (0,1) | (2,3,4) in polynomial arithmetic.
+PA_HD void p4pf_charpoly(const double (&a)[50], double (&p)[11])
+{
+    double c0[5][4], c1[5][3], c2[5][3], c3[5][3], c4[5][2];
+#pragma unroll
+    for (int r = 0; r < 5; ++r) {
+        const double *ar = a + 10 * r;
+        c0[r][0] = ar[0]; c0[r][1] = ar[1]; c0[r][2] = ar[5]; c0[r][3] = r == 0 ? -1.0 : 0.0;
+        c1[r][0] = ar[2]; c1[r][1] = ar[6]; c1[r][2] = r == 1 ? -1.0 : 0.0;
+        c2[r][0] = ar[3]; c2[r][1] = ar[7]; c2[r][2] = r == 2 ? -1.0 : 0.0;
+        c3[r][0] = ar[4]; c3[r][1] = ar[8]; c3[r][2] = r == 3 ? -1.0 : 0.0;
+        c4[r][0] = ar[9]; c4[r][1] = r == 4 ? -1.0 : 0.0;
+    }
+    // 2x2 minors of columns (3,4): n34[x][y], x < y, degree 3
+    double n34[5][5][4];
+#pragma unroll
+    for (int x = 0; x < 5; ++x)
+#pragma unroll
+        for (int y = x + 1; y < 5; ++y) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) n34[x][y][i] = 0.0;
+            poly_mac<3, 2>(n34[x][y], c3[x], c4[y], 1.0);
+            poly_mac<3, 2>(n34[x][y], c3[y], c4[x], -1.0);
+        }
+#pragma unroll
+    for (int i = 0; i < 11; ++i) p[i] = 0.0;
+#pragma unroll
+    for (int i = 0; i < 5; ++i)
+#pragma unroll
+        for (int j = i + 1; j < 5; ++j) {
+            // complement rows k < l < m
+            int rest[3], nr = 0;
+#pragma unroll
+            for (int t = 0; t < 5; ++t) if (t != i && t != j) rest[nr++] = t;
+            const int k = rest[0], l = rest[1], m = rest[2];
+            double M2[6] = {0, 0, 0, 0, 0, 0}, M3[6] = {0, 0, 0, 0, 0, 0};
+            poly_mac<4, 3>(M2, c0[i], c1[j], 1.0);
+            poly_mac<4, 3>(M2, c0[j], c1[i], -1.0);
+            poly_mac<3, 4>(M3, c2[k], n34[l][m], 1.0);
+            poly_mac<3, 4>(M3, c2[l], n34[k][m], -1.0);
+            poly_mac<3, 4>(M3, c2[m], n34[k][l], 1.0);
+            // sign of the Laplace term: (-1)^(i + j + 0 + 1)
+            poly_mac<6, 6>(p, M2, M3, ((i + j + 1) & 1) ? -1.0 : 1.0);
+        }
+}
+
+// Action-matrix rows 5..9 (a[50], row-major 5x10) -> accepted roots, ascending zd.
+// Returns the count (0..6), or -1 when an eigenvector component is not finite.
+PA_HD int p4pf_roots_sextic(const double (&a)[50], const p4pf_problem &pb, p4pf_root roots[10])
+{
+    double p[11];
+    p4pf_charpoly(a, p);
+    // remove L^2 and ee(L) = |d|^2 L^2 - 2 a.d L + |a|^2
+    const double ax = pb.m2D[0], ay = pb.m2D[1], dx = pb.m2D[6], dy = pb.m2D[7];
+    const double e0 = ax * ax + ay * ay, e1 = -2.0 * (ax * dx + ay * dy), e2 = dx * dx + dy * dy;
+    // Composite deflation: the quotient's high-order coefficients come from dividing top-down,
+    // the low-order ones from dividing bottom-up (each direction is accurate at its own end,
+    // whatever the magnitude spread of the coefficients); they are joined where they agree best.
+    double qt[7], qb[7], q[7];
+    qt[6] = p[10] / e2;
+    qt[5] = (p[9] - e1 * qt[6]) / e2;
+#pragma unroll
+    for (int k = 4; k >= 0; --k) qt[k] = (p[k + 4] - e1 * qt[k + 1] - e0 * qt[k + 2]) / e2;
+    qb[0] = p[2] / e0;
+    qb[1] = (p[3] - e1 * qb[0]) / e0;
+#pragma unroll
+    for (int k = 2; k <= 6; ++k) qb[k] = (p[k + 2] - e1 * qb[k - 1] - e2 * qb[k - 2]) / e0;
+    int join = 0;
+    double best = 1e300;
+#pragma unroll
+    for (int k = 0; k < 7; ++k) {
+        const double den = fabs(qt[k]) + fabs(qb[k]);
+        const double rel = den > 0.0 ? fabs(qt[k] - qb[k]) / den : 0.0;
+        if (rel < best) { best = rel; join = k; }
+    }
+#pragma unroll
+    for (int k = 0; k < 7; ++k) q[k] = k < join ? qb[k] : qt[k];
+    double sc = 0.0;
+#pragma unroll
+    for (int i = 0; i < 7; ++i) sc = fmax(sc, fabs(q[i]));
+    if (!(sc > 0.0) || !(sc < 1.79e308)) return -1;
+    double qr[7];
+#pragma unroll
+    for (int i = 0; i < 7; ++i) { q[i] /= sc; }
+#pragma unroll
+    for (int i = 0; i < 7; ++i) qr[i] = q[6 - i];
+    // |L| <= 1 from q, |L| > 1 from the reversed polynomial (mu = 1/L in (-1, 1))
+    double lam[12];
+    double r1[6], r2[6];
+    const int n1 = poly_roots<6>::find(q, -1.0, 1.0, r1);
+    const int n2 = poly_roots<6>::find(qr, -1.0, 1.0, r2);
+    int nl = 0;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) if (i < n1) { lam[nl < 12 ? nl : 0] = r1[i]; ++nl; }
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+        if (i < n2 && fabs(r2[i]) < 1.0 && r2[i] != 0.0) { lam[nl < 12 ? nl : 0] = 1.0 / r2[i]; ++nl; }
+    if (nl > 10) nl = 10;
+    // derivative of the characteristic polynomial for the Newton polish
+    double dp[10];
+#pragma unroll
+    for (int i = 0; i < 10; ++i) dp[i] = (i + 1) * p[i + 1];
+    int n = 0;
+    bool nan = false;
+    for (int t = 0; t < nl; ++t) {
+        double L = lam[t];
+        double S[5][5], y[4];
+        for (int it = 0; it < 4; ++it) {
+            p4pf_build_system(a, L, S);
+            const double f = -p4pf_solve_system(S, y);      // = charpoly(L)
+            const double df = poly_eval<9>(dp, L);
+            const double Ln = L - f / df;
+            if (!(Ln == Ln) || fabs(Ln - L) > 0.05 * fmax(1.0, fabs(L))) break;
+            const bool conv = fabs(Ln - L) <= 1e-15 * fmax(1.0, fabs(L));
+            L = Ln;
+            if (conv) break;
+        }
+        p4pf_build_system(a, L, S);
+        p4pf_solve_system(S, y);
+        const double zc = y[0], zb = y[1], w = y[2];
+        if (!(zc == zc) || !(zb == zb) || !(w == w)) nan = true;
+        if (w > 0.00001) {
+            p4pf_root rt;
+            rt.f = sqrt(w); rt.zd = L; rt.zc = zc; rt.zb = zb;
+            // insertion by ascending zd
+            int pos = n;
+            for (int j = n - 1; j >= 0 && roots[j].zd > rt.zd; --j) { roots[j + 1] = roots[j]; pos = j; }
+            roots[pos] = rt;
+            ++n;
+        }
+    }
+    return nan ? -1 : n;
+}
+
+#undef PA_HD
+} // namespace pose_amd

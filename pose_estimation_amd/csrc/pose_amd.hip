@@ -36,7 +36,7 @@ struct pose_amd_ctx {
     // hypotheses
     uint32_t hyp_count = 0;
     int solver = POSE_AMD_SOLVER_P4PF;
-    dev_buf samples, sample_status, proj, pose, nsol, counts, sel, ws, bitmaps, areas, maskw, arows, pstatus;
+    dev_buf samples, sample_status, proj, pose, nsol, counts, sel, bitmaps, areas, maskw, arows, pstatus;
     // scratch for batch entry points
     dev_buf in0, in1, in2, out0, out1, out2, out3;
     // last run
@@ -44,7 +44,6 @@ struct pose_amd_ctx {
     double best_proj[12];
     double last_eps = 0.5;
     float last_ms[4] = {0, 0, 0, 0};
-    size_t ws_lanes = 0;
 };
 
 #define HIPCHK(ctx, call)                                                                                  \
@@ -100,18 +99,6 @@ static query_dev make_query(const pose_amd_ctx *c)
 
 static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 
-// Lanes (and workspace) used by the template P4Pf kernels.
-static int ensure_ws(pose_amd_ctx *ctx, size_t problems, int &blocks)
-{
-    size_t lanes = (size_t)ctx->cus * 4 * 64;          // 4 waves per CU in flight
-    if (lanes == 0) lanes = 256 * 4 * 64;
-    size_t need = ((problems + 63) / 64) * 64;
-    if (need < lanes) lanes = need;
-    blocks = (int)(lanes / 64);
-    ctx->ws_lanes = lanes;
-    return ensure(ctx, ctx->ws, lanes * 78 * 88 * sizeof(double));
-}
-
 // P4Pf minimal solves for `count` hypotheses: cooperative elimination, then per-lane eigen
 // step and pose recovery.  Exactly one of (samples) / (m2d, M3D) is given.
 static int launch_p4pf(pose_amd_ctx *ctx, uint32_t count, const uint32_t *samples, const double *m2d, const double *M3D,
@@ -160,9 +147,6 @@ int pose_amd_create(int device, pose_amd_ctx **out)
     if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
     for (int i = 0; i < 4; ++i)
         if ((e = hipEventCreate(&c->ev[i])) != hipSuccess) return bail("hipEventCreate", e);
-    if ((e = hipMemcpyToSymbol(HIP_SYMBOL(c_tpl_row), P4PF_TPL_ROW, P4PF_TPL_NNZ)) != hipSuccess) return bail("template upload", e);
-    if ((e = hipMemcpyToSymbol(HIP_SYMBOL(c_tpl_col), P4PF_TPL_COL, P4PF_TPL_NNZ)) != hipSuccess) return bail("template upload", e);
-    if ((e = hipMemcpyToSymbol(HIP_SYMBOL(c_tpl_coef), P4PF_TPL_COEF, P4PF_TPL_NNZ)) != hipSuccess) return bail("template upload", e);
     // co-occurrence gain table of the advanced sampler (query_processor_advanced.cpp:391-392)
     std::vector<double> gain(MAXCAM + 1);
     for (int cs = 0; cs <= MAXCAM; ++cs) gain[cs] = 1.0 / (1.0 + std::exp(-(double)((float)cs / 5.0f)));
@@ -179,7 +163,7 @@ void pose_amd_destroy(pose_amd_ctx *c)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     dev_buf *bufs[] = {&c->kx, &c->ky, &c->X, &c->Y, &c->Z, &c->lindex, &c->cam_off, &c->cam_ids, &c->gain, &c->samples,
-                       &c->sample_status, &c->proj, &c->pose, &c->nsol, &c->counts, &c->sel, &c->ws, &c->bitmaps, &c->areas,
+                       &c->sample_status, &c->proj, &c->pose, &c->nsol, &c->counts, &c->sel, &c->bitmaps, &c->areas,
                        &c->maskw, &c->arows, &c->pstatus, &c->in0, &c->in1, &c->in2, &c->out0, &c->out1, &c->out2, &c->out3};
     for (dev_buf *b : bufs) if (b->p) (void)hipFree(b->p);
     for (int i = 0; i < 4; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);

@@ -1,5 +1,6 @@
 // Debug harness: cooperative elimination vs the per-lane template LU on the same problems.
 #include "../pose_estimation_amd/csrc/kernels.h"
+#include "../pose_estimation_amd/csrc/p4pf_template_dev.h"
 #include <cstdio>
 #include <vector>
 #include <random>

@@ -1,6 +1,7 @@
 // Micro-benchmark: splits the template P4Pf solver into (a) fill + LU + action matrix and
 // (b) eigen-decomposition + pose recovery, and times each with HIP events.
 #include "../pose_estimation_amd/csrc/kernels.h"
+#include "../pose_estimation_amd/csrc/p4pf_template_dev.h"
 #include <cstdio>
 #include <vector>
 #include <random>
