@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpose_amd.so")
+LIB_PATH = os.environ.get("POSE_AMD_LIB") or os.path.join(_HERE, "libpose_amd.so")   # override: experiments with other builds
 
 
 class PoseAmdError(RuntimeError):

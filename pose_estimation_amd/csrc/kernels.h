@@ -211,7 +211,7 @@ __device__ __forceinline__ void p4pf_fetch(const query_dev &q, const uint32_t *_
     }
 }
 
-__global__ __launch_bounds__(64) void k_p4pf_elim(query_dev q, uint32_t hyp_count, const uint32_t *__restrict__ samples,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_p4pf_elim(query_dev q, uint32_t hyp_count, const uint32_t *__restrict__ samples,
                                                   const double *__restrict__ m2d_in, const double *__restrict__ M3D_in,
                                                   double *__restrict__ Arows, int *__restrict__ status)
 {
@@ -223,30 +223,33 @@ __global__ __launch_bounds__(64) void k_p4pf_elim(query_dev q, uint32_t hyp_coun
         if (lane < ELIM_BATCH) {
             const size_t h = (size_t)b * ELIM_BATCH + lane;
             int st = -1;
+            double k[42];
+#pragma unroll
+            for (int g = 0; g < 42; ++g) k[g] = 0.0;
             if (h < hyp_count) {
-                double m2d[8], M3D[12], k[42];
+                double m2d[8], M3D[12];
                 p4pf_fetch(q, samples, m2d_in, M3D_in, h, m2d, M3D);
                 p4pf_problem pb;
                 st = p4pf_normalise(m2d, M3D, pb);
-                p4pf_coefs(pb.gl[0], pb.gl[1], pb.gl[2], pb.gl[3], pb.gl[4], pb.gl[5], pb.m2D[0], pb.m2D[1], pb.m2D[2], pb.m2D[3],
-                           pb.m2D[4], pb.m2D[5], pb.m2D[6], pb.m2D[7], k);
-#pragma unroll
-                for (int g = 0; g < 42; ++g) cf[lane][g] = k[g];
-                cf[lane][42] = 0.0;
+                if (st == 0)
+                    p4pf_coefs(pb.gl[0], pb.gl[1], pb.gl[2], pb.gl[3], pb.gl[4], pb.gl[5], pb.m2D[0], pb.m2D[1], pb.m2D[2], pb.m2D[3],
+                               pb.m2D[4], pb.m2D[5], pb.m2D[6], pb.m2D[7], k);
             }
+#pragma unroll
+            for (int g = 0; g < 42; ++g) cf[lane][g] = k[g];
+            cf[lane][42] = 0.0;
             st_s[lane] = st;
         }
         __syncthreads();
-        for (int i = 0; i < ELIM_BATCH; ++i) {
-            const size_t h = (size_t)b * ELIM_BATCH + i;
-            if (h >= hyp_count) break;
-            const int st = __builtin_amdgcn_readfirstlane(st_s[i]);
-            if (st != 0) { if (lane == 0) status[h] = -1; continue; }
-            double k[42];
-#pragma unroll
-            for (int g = 0; g < 42; ++g) k[g] = wave_uniform(cf[i][g]);
-            const int rc = p4pf_elim_wave(k, &cf[i][0], Arows + h * 50);
-            if (lane == 0) status[h] = rc;
+        // two systems per pass: lanes 0..31 eliminate system 2i, lanes 32..63 system 2i+1
+        for (int i = 0; i < ELIM_BATCH / 2; ++i) {
+            const int sys = 2 * i + (lane >> 5);
+            const size_t h = (size_t)b * ELIM_BATCH + sys;
+            if ((size_t)b * ELIM_BATCH + 2 * i >= hyp_count) break;
+            const int st = st_s[sys];
+            const bool live = h < hyp_count;
+            const int rc = p4pf_elim_wave(&cf[sys][0], Arows + (live ? h : 0) * 50, live && st == 0);
+            if ((lane & 31) == 0 && live) status[h] = st != 0 ? -1 : rc;
         }
         __syncthreads();
     }

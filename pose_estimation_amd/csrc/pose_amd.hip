@@ -495,7 +495,7 @@ int pose_amd_ransac_run(pose_amd_ctx *ctx, const pose_amd_params *prm, pose_amd_
     const int maxsol = ctx->solver == POSE_AMD_SOLVER_P4PF ? P4PF_MAXSOL : P3P_MAXSOL;
     // Hypotheses are evaluated speculatively in chunks; the selection below replays them in
     // order, so the outcome equals the reference's one-step-at-a-time loop.
-    const uint32_t chunk = std::min<uint32_t>(H, prm->early_exit ? 2048u : 131072u);
+    const uint32_t chunk = std::min<uint32_t>(H, prm->early_exit ? 2048u : 524288u);
     const size_t cslots = (size_t)chunk * maxsol;
     int rc;
     if ((rc = ensure(ctx, ctx->proj, cslots * 96)) || (rc = ensure(ctx, ctx->pose, cslots * 104)) ||

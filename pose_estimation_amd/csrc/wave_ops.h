@@ -42,4 +42,34 @@ __device__ __forceinline__ int wave_argmax_abs(double x, bool cand)
     return (int)__builtin_ctzll(who | (1ull << 63));
 }
 
+// ---- the same for two independent 32-lane halves of a wave --------------------------------
+
+// Value of `v` in lane `src` (an absolute lane number; every lane of a half passes the same
+// one) through the LDS crossbar: two ds_bpermute_b32, no LDS memory is touched.
+__device__ __forceinline__ double half_bcast(double v, int src)
+{
+    const int lo = __builtin_amdgcn_ds_bpermute(src << 2, __double2loint(v));
+    const int hi = __builtin_amdgcn_ds_bpermute(src << 2, __double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+
+// Absolute lane number, inside the caller's own 32-lane half, of the candidate with the
+// largest |x| (float32 key, lowest lane on ties); the first lane of the half if there is none.
+__device__ __forceinline__ int half_argmax_abs(double x, bool cand)
+{
+    const unsigned key = cand ? (__float_as_uint((float)fabs(x)) + 1u) : 0u;
+    unsigned m = key;
+    m = max(m, (unsigned)__builtin_amdgcn_update_dpp(0, (int)m, 0xB1, 0xf, 0xf, true));
+    m = max(m, (unsigned)__builtin_amdgcn_update_dpp(0, (int)m, 0x4E, 0xf, 0xf, true));
+    m = max(m, (unsigned)__builtin_amdgcn_update_dpp(0, (int)m, 0x141, 0xf, 0xf, true));
+    m = max(m, (unsigned)__builtin_amdgcn_update_dpp(0, (int)m, 0x140, 0xf, 0xf, true));
+    // combine the two rows of 16 lanes of each half: ds_swizzle bit mode, lane ^ 16
+    m = max(m, (unsigned)__builtin_amdgcn_ds_swizzle((int)m, 0x401F));
+    const unsigned long long who = __ballot(key == m && cand);
+    const unsigned lo = (unsigned)who, hi = (unsigned)(who >> 32);
+    const bool upper = (threadIdx.x & 32) != 0;
+    const unsigned mine = upper ? hi : lo;
+    return (upper ? 32 : 0) + (mine ? (int)__builtin_ctz(mine) : 0);
+}
+
 } // namespace pose_amd

@@ -4,14 +4,16 @@ elimination of the 78x88 P4Pf template (reference P4pf.cpp:959-1109).
 
 What the reference computes: Mr = M_left^-1 M_right (78x78 partial-pivot LU, 10 right-hand
 sides), of which only rows 70..74 feed the action matrix.  Equivalent elimination used here
-(one system per 64-lane wave, one matrix ROW per lane, columns = named registers):
+(TWO systems per 64-lane wave, one per 32-lane half; one matrix ROW per lane, columns = named
+registers):
 
   stage 1  49 eliminations whose pivot is one of the template's constant entries (1, -1, -2).
-           45 of the pivot rows are still in their original form when used, so their entries
-           are plain template coefficients (wave-uniform operands): no cross-lane traffic.
-           Only rows that get modified are materialised in lanes (29 survivors + 4 pivots).
+           The order is chosen so that every pivot row is still in its original form when it
+           is used: its entries are plain template coefficients, the same for all lanes of a
+           half, so no cross-lane traffic is needed and the pivot rows never occupy a lane.
+           Only the 29 rows that survive stage 1 are materialised (lanes 0..28 of each half).
   stage 2  the remaining 24 columns, dynamic partial pivoting over the 29 surviving rows
-           (wave arg-max, pivot row broadcast lane -> scalar registers).
+           (arg-max inside each half, pivot row broadcast with ds_bpermute).
   stage 3  Gauss-Jordan on the 5 needed columns (70..74) of the last 5 rows.
 
 The script also contains a NumPy interpreter of the same schedule (used by
@@ -26,6 +28,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CONST = {0: 1.0, 2: -1.0, 3: -1.0, 12: 1.0, 14: -2.0, 22: 1.0, 24: -1.0, 32: 1.0, 34: -1.0}
+LDS_SHARE = int(os.environ.get("P4PF_ELIM_LDS_SHARE", "5"))   # of every 8 pivot-row broadcasts, how many go through the LDS crossbar
 KEEP = list(range(70, 75))          # columns whose rows of Mr are needed
 RHS = list(range(78, 88))
 
@@ -54,6 +57,16 @@ def build_schedule():
     def colrows(c):
         return sorted(r for r in active if c in rows[r])
 
+    def harm(targets, pc):
+        # number of targets that are still unmodified and could serve as a constant pivot later
+        n = 0
+        for t in targets:
+            if t in modified:
+                continue
+            if any(e[0] == "c" and cc != pc and cc not in done and cc not in KEEP and cc < 78 for cc, e in rows[t].items()):
+                n += 1
+        return n
+
     while True:
         best = None
         for c in elim_cols:
@@ -65,7 +78,7 @@ def build_schedule():
                 if e[0] != "c":
                     continue
                 cost = (len(rs) - 1) * (len(rows[r]) - 1)
-                key = (r in modified, cost, c, r)
+                key = (r in modified, harm([x for x in rs if x != r], c), cost, c, r)
                 if best is None or key < best[0]:
                     best = (key, r, c)
         if best is None:
@@ -94,8 +107,9 @@ def build_schedule():
         steps.append(dict(row=pr, col=pc, pv=pv, materialised=pr in modified, pattern=pattern, targets=targets))
     survivors = sorted(active)
     mat_rows = sorted(modified)                       # rows that live in lanes
-    assert set(survivors) <= set(mat_rows) or True
+    assert not any(st["materialised"] for st in steps), "a pivot row was modified before use"
     lanes_rows = sorted(set(mat_rows) | set(survivors))
+    assert lanes_rows == survivors and len(lanes_rows) <= 32
     lane_of = {r: i for i, r in enumerate(lanes_rows)}
     # stage 2: static column order with worst-case (any candidate may be pivot) fill
     pat = {r: set(rows[r].keys()) for r in survivors}
@@ -201,41 +215,71 @@ def emit(sched):
     lanes_rows, lane_of = sched["lanes_rows"], sched["lane_of"]
     nl = len(lanes_rows)
     w("// GENERATED by tools/gen_p4pf_elim.py -- do not edit.")
-    w("// Wave-cooperative elimination of the 78x88 P4Pf template: one system per wave, one")
-    w("// matrix row per lane, one named register per column.  See the generator for the schedule.")
+    w("// Wave-cooperative elimination of the 78x88 P4Pf template: two systems per wave (one per")
+    w("// 32-lane half), one matrix row per lane, one named register per column.  See the generator")
+    w("// for the schedule.")
     w("#pragma once")
     w("namespace pose_amd {")
-    w(f"constexpr int P4PF_ELIM_LANES = {nl};   // lanes that hold a matrix row")
-    # init table: for each lane and column the coefficient id (42 = structural zero)
-    tbl = np.full((64, 88), 42, dtype=np.int64)
+    w(f"constexpr int P4PF_ELIM_LANES = {nl};   // lanes of each half that hold a matrix row")
+    # init table: for each lane of a half and column the coefficient id (42 = structural zero)
+    tbl = np.full((32, 88), 42, dtype=np.int64)
     for r in lanes_rows:
         for c, g in sched["orig"][r].items():
             tbl[lane_of[r], c] = g
-    w("// coefficient id of entry (lane, column) of the initial matrix; 42 = structural zero")
-    w("__constant__ unsigned char c_elim_init[88][64] = {")
+    w("// coefficient id of entry (lane & 31, column) of the initial matrix; 42 = structural zero")
+    w("__constant__ unsigned char c_elim_init[88][32] = {")
     for c in range(88):
         w("  {" + ",".join(str(int(v)) for v in tbl[:, c]) + "},")
     w("};")
     w("")
-    w("// k: the 42 template coefficients of this wave's system, wave-uniform.")
-    w("// cf: LDS array of 43 doubles holding k[0..41] and 0.0 at index 42 (same for all lanes).")
-    w("// Returns 0, or -1 when a pivot is exactly zero.  out5x10[(i-5)*10 + j] = A(i, j), i = 5..9,")
-    w("// written by single lanes.")
-    w("__device__ __forceinline__ int p4pf_elim_wave(const double (&k)[42], const double *cf, double *out5x10)")
+    w("// cf: LDS array of 43 doubles holding the 42 template coefficients of this lane's system and")
+    w("// 0.0 at index 42 (the pointer differs between the two halves of the wave).")
+    w("// Returns 0, or -1 when a pivot is exactly zero (same value in all lanes of a half).")
+    w("// out5x10[(i-5)*10 + j] = A(i, j), i = 5..9, written by single lanes of each half when wr is set.")
+    w("__device__ __forceinline__ int p4pf_elim_wave(const double *cf, double *out5x10, bool wr)")
     w("{")
     w("    const int lane = (int)(threadIdx.x & 63);")
+    w("    const int row = lane & 31;")
+    w("    const bool upper = lane >= 32;")
     w("    int bad = 0;")
     initialised = set()
+    kdone = set()
 
     def need(c):
         if c not in initialised:
             initialised.add(c)
-            w(f"    double r{c} = cf[c_elim_init[{c}][lane]];")
+            w(f"    double r{c} = cf[c_elim_init[{c}][row]];")
 
     def kexpr(g):
         if g in CONST:
             return repr(CONST[g])
-        return f"k[{g}]"
+        if g not in kdone:
+            kdone.add(g)
+            w(f"    const double k{g} = cf[{g}];")
+        return f"k{g}"
+
+    # Pivot-row broadcast, per 32-lane half.  Two routes share the work so that neither pipe is the
+    # bottleneck: the LDS crossbar (ds_bpermute, both halves in one instruction) and the vector
+    # ALU (v_readlane of each half's pivot lane into scalar registers, then a half-masked fma).
+    def bcast_fma(cols, chunk_size):
+        for i0 in range(0, len(cols), chunk_size):
+            chunk = cols[i0:i0 + chunk_size]
+            nl_ = (len(chunk) * LDS_SHARE + 7) // 8 if LDS_SHARE < 8 else len(chunk)
+            via_lds, via_alu = chunk[:nl_], chunk[nl_:]
+            for c2 in via_lds:
+                w(f"        const double e{c2} = half_bcast(r{c2}, L);")
+            for c2 in via_alu:
+                w(f"        const double a{c2} = wave_bcast(r{c2}, L0), b{c2} = wave_bcast(r{c2}, L1);")
+            for c2 in via_lds:
+                w(f"        r{c2} = fma(m, e{c2}, r{c2});")
+            if via_alu:
+                w("        if (upper) {")
+                for c2 in via_alu:
+                    w(f"            r{c2} = fma(m, b{c2}, r{c2});")
+                w("        } else {")
+                for c2 in via_alu:
+                    w(f"            r{c2} = fma(m, a{c2}, r{c2});")
+                w("        }")
 
     # ---- stage 1
     for si, st in enumerate(sched["steps"]):
@@ -243,49 +287,30 @@ def emit(sched):
         need(pc)
         for c2 in st["pattern"]:
             need(c2)
-        w(f"    {{ // stage 1 step {si}: column {pc}, pivot row {st['row']} ({'lane ' + str(lane_of[st['row']]) if st['materialised'] else 'original form'})")
-        if st["materialised"]:
-            L = lane_of[st["row"]]
-            w(f"        double m = lane == {L} ? 0.0 : r{pc} * {repr(-1.0 / pv)};")
-            pat = st["pattern"]
-            for c2 in pat:
-                need(c2)
-            for i0 in range(0, len(pat), 8):
-                chunk = pat[i0:i0 + 8]
-                for c2 in chunk:
-                    w(f"        const double e{c2} = wave_bcast(r{c2}, {L});")
-                for c2 in chunk:
-                    w(f"        r{c2} = fma(m, e{c2}, r{c2});")
-        else:
-            w(f"        const double m = r{pc} * {repr(-1.0 / pv)};")
-            for c2 in st["pattern"]:
-                need(c2)
-                g = sched["orig"][st["row"]][c2]
-                w(f"        r{c2} = fma(m, {kexpr(g)}, r{c2});")
+        ops = [(c2, kexpr(sched["orig"][st["row"]][c2])) for c2 in st["pattern"]]
+        w(f"    {{ // stage 1 step {si}: column {pc}, pivot row {st['row']} (original form)")
+        w(f"        const double m = r{pc} * {repr(-1.0 / pv)};")
+        for c2, ke in ops:
+            w(f"        r{c2} = fma(m, {ke}, r{c2});")
         w("    }")
     # ---- stage 2
     surv_lanes = sorted(lane_of[r] for r in sched["survivors"])
     mask = 0
     for L in surv_lanes:
         mask |= 1 << L
-    w(f"    bool active = ((0x{mask:x}ull >> lane) & 1ull) != 0;   // the {len(surv_lanes)} surviving rows")
+    w(f"    bool active = ((0x{mask:x}u >> row) & 1u) != 0;   // the {len(surv_lanes)} surviving rows")
     for si, st in enumerate(sched["stage2"]):
         c = st["col"]
         need(c)
         for c2 in st["pattern"]:
             need(c2)
         w(f"    {{ // stage 2 step {si}: column {c}")
-        w(f"        const int L = wave_argmax_abs(r{c}, active);")
-        w(f"        const double pv = wave_bcast_dyn(r{c}, L);")
+        w(f"        const int L = half_argmax_abs(r{c}, active);")
+        w("        const int L0 = __builtin_amdgcn_readfirstlane(L), L1 = __builtin_amdgcn_readlane(L, 32);")
+        w(f"        const double pv = half_bcast(r{c}, L);")
         w("        bad |= pv == 0.0;")
         w(f"        const double m = (active && lane != L) ? -r{c} / pv : 0.0;")
-        pat = st["pattern"]
-        for i0 in range(0, len(pat), 8):
-            chunk = pat[i0:i0 + 8]
-            for c2 in chunk:
-                w(f"        const double e{c2} = wave_bcast_dyn(r{c2}, L);")
-            for c2 in chunk:
-                w(f"        r{c2} = fma(m, e{c2}, r{c2});")
+        bcast_fma(st["pattern"], 8)
         w("        active = active && lane != L;")
         w("    }")
     # ---- stage 3
@@ -296,16 +321,12 @@ def emit(sched):
     for c in KEEP:
         others = [c2 for c2 in KEEP + RHS if c2 != c]
         w(f"    {{ // stage 3: column {c}")
-        w(f"        const int L = wave_argmax_abs(r{c}, pool);")
-        w(f"        const double pv = wave_bcast_dyn(r{c}, L);")
+        w(f"        const int L = half_argmax_abs(r{c}, pool);")
+        w("        const int L0 = __builtin_amdgcn_readfirstlane(L), L1 = __builtin_amdgcn_readlane(L, 32);")
+        w(f"        const double pv = half_bcast(r{c}, L);")
         w("        bad |= pv == 0.0;")
         w(f"        const double m = (active && lane != L) ? -r{c} / pv : 0.0;")
-        for i0 in range(0, len(others), 7):
-            chunk = others[i0:i0 + 7]
-            for c2 in chunk:
-                w(f"        const double e{c2} = wave_bcast_dyn(r{c2}, L);")
-            for c2 in chunk:
-                w(f"        r{c2} = fma(m, e{c2}, r{c2});")
+        bcast_fma(others, 7)
         w(f"        r{c} = lane == L ? r{c} : 0.0;   // the column is now eliminated from every other row")
         w("        pool = pool && lane != L;")
         w(f"        lane_of_col[{c - 70}] = L;")
@@ -313,7 +334,7 @@ def emit(sched):
     w("    // every pivot row is now reduced: row i of the action matrix is A(i, j) = -Mr(79 - i, 9 - j)")
     for c in KEEP:
         i = 79 - c
-        w(f"    if (lane == lane_of_col[{c - 70}]) {{")
+        w(f"    if (wr && lane == lane_of_col[{c - 70}]) {{")
         w(f"        const double s = -1.0 / r{c};")
         w(f"        double *o = out5x10 + {(i - 5) * 10};")
         for j in range(10):
@@ -329,8 +350,7 @@ def emit(sched):
 if __name__ == "__main__":
     s = build_schedule()
     n1 = len(s["steps"])
-    print("stage 1: %d constant-pivot steps (%d with materialised pivot rows), %d rows in lanes, %d survivors"
-          % (n1, sum(st["materialised"] for st in s["steps"]), len(s["lanes_rows"]), len(s["survivors"])))
+    print("stage 1: %d constant-pivot steps, %d rows in lanes" % (n1, len(s["lanes_rows"])))
     print("stage 1 fma count:", sum(len(st["pattern"]) for st in s["steps"]))
     print("stage 2: %d columns, broadcast+fma count %d" % (len(s["stage2"]), sum(len(st["pattern"]) for st in s["stage2"])))
     out = os.path.join(ROOT, "pose_estimation_amd", "csrc", "p4pf_elim_gen.h")
