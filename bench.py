@@ -26,7 +26,10 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 FP64_VECTOR_PEAK_TFLOPS = 78.6     # MI355X fp64 vector peak: 256 CU x 4 SIMD x 16 FMA lanes/clk x 2 x 2.4 GHz
 HBM_PEAK_GBS = 8000.0
-SCORE_FLOP_PER_PAIR = 28           # 11 FMA + 4 MUL + 1 compare per (pose, correspondence), see DESIGN.md
+# Algorithmic fp64 work per unit of each kernel (derivations in DESIGN.md):
+SCORE_FLOP_PER_PAIR = 27           # reference formula per (pose, correspondence): 3x4 product, 2 div, distance, compare
+ELIM_FLOP_PER_HYP = 2.34e4         # sparsity-exploiting elimination of the 78x88 template (22 920) + coefficient formulas
+FINISH_FLOP_PER_HYP = 8.9e4        # executed fp64 lane-operations per hypothesis, from SQ_INSTS_VALU_*_F64 (profiles/)
 
 
 def main():
@@ -82,14 +85,14 @@ def main():
         step(i)
     sync()
     t0 = time.perf_counter()
-    tim = dict(solve_ms=0.0, score_ms=0.0, select_ms=0.0, total_ms=0.0)
+    tim = {}
     poses = 0
     last = None
     for i in range(args.steps):
         last = step(args.warmup + i)
         poses += last["poses_scored"]
         for k, v in ctx.last_timing().items():
-            tim[k] += v
+            tim[k] = tim.get(k, 0.0) + v
     sync()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -100,16 +103,22 @@ def main():
     if rank == 0:
         total_hyps = H * args.steps * world
         info = ctx.device_info()
-        # dominant kernel of the step and its roofline (HIP-event times from the library's stream)
-        solve_s, score_s = tim["solve_ms"] / 1e3, tim["score_ms"] / 1e3
-        pairs = poses * args.matches
-        score_tflops = pairs * SCORE_FLOP_PER_PAIR / score_s / 1e12 if score_s > 0 else 0.0
-        roofline = {"kernel": "k_score", "bound": "valu_fp64", "achieved": round(score_tflops, 3),
-                    "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(score_tflops / FP64_VECTOR_PEAK_TFLOPS, 4),
-                    "traffic": None,
-                    "kernel_ms": {k: round(v / args.steps, 3) for k, v in tim.items()},
-                    "poses_per_hypothesis": round(poses / (H * args.steps), 3),
-                    "dominant": "solve" if solve_s > score_s else "score"}
+        # Roofline of the dominant kernel of the step.  Durations are HIP-event times taken by the
+        # library on its own stream around each kernel, averaged over the launches of the timed steps.
+        launches = max(int(tim["launches"]), 1)
+        hyps_rank = H * args.steps
+        work = {"k_p4pf_elim": (tim["elim_ms"], hyps_rank * ELIM_FLOP_PER_HYP),
+                "k_p4pf_finish": (tim["finish_ms"], hyps_rank * FINISH_FLOP_PER_HYP),
+                "k_score": (tim["score_ms"], poses * args.matches * SCORE_FLOP_PER_PAIR)}
+        dom = max(work, key=lambda k: work[k][0])
+        dom_ms, dom_flop = work[dom]
+        tflops = dom_flop / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
+        roofline = {"kernel": dom, "bound": "valu_fp64", "achieved": round(tflops, 3), "peak": FP64_VECTOR_PEAK_TFLOPS,
+                    "unit": "TFLOP/s", "frac": round(tflops / FP64_VECTOR_PEAK_TFLOPS, 4), "traffic": recorded_traffic(dom),
+                    "launches": launches, "avg_launch_ms": round(dom_ms / launches, 4),
+                    "kernel_ms_per_step": {k: round(v / args.steps, 3) for k, v in tim.items() if k.endswith("_ms")},
+                    "kernel_tflops": {k: round(f / (ms * 1e-3) / 1e12, 3) for k, (ms, f) in work.items() if ms > 0},
+                    "poses_per_hypothesis": round(poses / hyps_rank, 3)}
         out = {"metric": "RANSAC hypotheses/sec (P4Pf solve+score)", "value": round(total_hyps / dt, 1), "unit": "hypotheses/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
@@ -119,7 +128,7 @@ def main():
                           "device": info["name"], "best_inliers": int(last["inliers"])},
                "roofline": roofline}
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(q, args)
+            out["cpu_baseline"] = cpu_baseline(ctx, q, args)
         print(json.dumps(out))
     ctx.close()
     if world > 1:
@@ -127,24 +136,39 @@ def main():
     return 0
 
 
-def cpu_baseline(q, args):
+def recorded_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed counter passes (FETCH_SIZE doubled
+    as measured for gfx950, plus WRITE_SIZE), or None when no record exists for it."""
+    path = os.path.join(ROOT, "profiles", "r1_traffic.json")
+    try:
+        with open(path) as f:
+            return json.load(f).get(kernel, {}).get("hbm_bytes_per_launch")
+    except (OSError, ValueError):
+        return None
+
+
+def cpu_baseline(ctx, q, args):
     """The CPU oracle (a port of the reference's algorithm; the reference itself needs Eigen,
-    FLANN and OpenCV, which are not installed) on a bounded sample of the same workload."""
+    FLANN and OpenCV, which are not installed) on a bounded sample of the same workload: the
+    first `count` hypotheses of the benchmark's sample stream, OpenMP over hypotheses."""
     import oracle_lib as O
+    from pose_estimation_amd import SAMPLE_BASIC
     cores = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16")), 16)
-    n = len(q["kx"])
-    probe = np.array([O.sample_basic(1002, 0, h, 4, n)[0] for h in range(256)], np.uint32)
+    kw = (q["kx"], q["ky"], q["X"], q["Y"], q["Z"], q["width"], q["height"], 0.0)
+    probe = ctx.sample(SAMPLE_BASIC, 1002, 0, 0, 4096)
+    probe[:, 3] = np.where(probe[:, 3] == 0xFFFFFFFF, 0, probe[:, 3])
     t0 = time.perf_counter()
-    O.ransac_fixed_budget(q["kx"], q["ky"], q["X"], q["Y"], q["Z"], q["width"], q["height"], 0.0, probe, threads=cores)
-    per = (time.perf_counter() - t0) / 256
-    count = args.cpu_hyps or int(min(max(12.0 / max(per, 1e-7), 512), 200000))
-    samples = np.array([O.sample_basic(1002, 0, h, 4, n)[0] for h in range(count)], np.uint32)
+    O.ransac_fixed_budget(*kw, probe, threads=cores)
+    per = (time.perf_counter() - t0) / len(probe)
+    count = args.cpu_hyps or int(min(max(15.0 / max(per, 1e-8), 4096), 1 << 22))
+    samples = ctx.sample(SAMPLE_BASIC, 1002, 0, 0, count)
+    samples[:, 3] = np.where(samples[:, 3] == 0xFFFFFFFF, 0, samples[:, 3])
     t0 = time.perf_counter()
-    O.ransac_fixed_budget(q["kx"], q["ky"], q["X"], q["Y"], q["Z"], q["width"], q["height"], 0.0, samples, threads=cores)
+    O.ransac_fixed_budget(*kw, samples, threads=cores)
     dt = time.perf_counter() - t0
     return {"value": round(count / dt, 1), "unit": "hypotheses/s", "cores": cores, "kind": "port",
-            "sample": "%d hypotheses of the same query (same sampler stream), oracle/pose_oracle.c with OpenMP over hypotheses, %.1f s"
-                      % (count, dt)}
+            "sample": "first %d hypotheses of the same query and sample stream (tuples exported by the device sampler), "
+                      "oracle/pose_oracle.c with OpenMP over hypotheses, %.1f s" % (count, dt)}
 
 
 if __name__ == "__main__":

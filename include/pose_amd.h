@@ -126,8 +126,10 @@ int pose_amd_best_mask(pose_amd_ctx *ctx, uint8_t *mask);
 
 /* ---- measurement -------------------------------------------------------------------------- */
 /* Kernel time of the last pose_amd_ransac_run measured with HIP events on the context's
- * stream: ms[0] solve, ms[1] score, ms[2] select/reduce, ms[3] whole call (device side). */
-int pose_amd_last_timing(pose_amd_ctx *ctx, float ms[4]);
+ * stream, summed over the call's chunks: ms[0] solve (all solver kernels), ms[1] score,
+ * ms[2] select/reduce, ms[3] whole call (device side), ms[4] P4Pf elimination kernel,
+ * ms[5] P4Pf finish kernel, ms[6] number of chunks (= launches of each kernel), ms[7] 0. */
+int pose_amd_last_timing(pose_amd_ctx *ctx, float ms[8]);
 
 #ifdef __cplusplus
 }

@@ -186,9 +186,10 @@ class Context:
         return m
 
     def last_timing(self):
-        ms = (C.c_float * 4)()
+        ms = (C.c_float * 8)()
         self._chk(self._lib.pose_amd_last_timing(self._h, ms), "last_timing")
-        return dict(solve_ms=ms[0], score_ms=ms[1], select_ms=ms[2], total_ms=ms[3])
+        return dict(solve_ms=ms[0], score_ms=ms[1], select_ms=ms[2], total_ms=ms[3], elim_ms=ms[4], finish_ms=ms[5],
+                    launches=int(ms[6]))
 
     def synchronize(self):
         self._chk(self._lib.pose_amd_synchronize(self._h), "synchronize")

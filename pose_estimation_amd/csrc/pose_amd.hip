@@ -24,7 +24,7 @@ struct dev_buf {
 struct pose_amd_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
-    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     std::string err;
     char dev_name[256] = {0};
     int cus = 0, clock_khz = 0;
@@ -43,7 +43,7 @@ struct pose_amd_ctx {
     bool have_best = false;
     double best_proj[12];
     double last_eps = 0.5;
-    float last_ms[4] = {0, 0, 0, 0};
+    float last_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // solve, score, select, total, elimination kernel, finish kernel, chunks, 0
 };
 
 #define HIPCHK(ctx, call)                                                                                  \
@@ -112,6 +112,7 @@ static int launch_p4pf(pose_amd_ctx *ctx, uint32_t count, const uint32_t *sample
     hipLaunchKernelGGL(k_p4pf_elim, dim3(std::min(nbatch, max_blocks)), dim3(64), 0, ctx->stream, q, count, samples, m2d, M3D,
                        (double *)ctx->arows.p, (int *)ctx->pstatus.p);
     HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipEventRecord(ctx->ev[4], ctx->stream));     // end of the elimination kernel, for the per-kernel timing
     hipLaunchKernelGGL(k_p4pf_finish, dim3(cdiv(count, 64)), dim3(64), 0, ctx->stream, q, count, samples, m2d, M3D,
                        (const double *)ctx->arows.p, (const int *)ctx->pstatus.p, proj, pose, nsol, fo, Ro, to);
     HIPCHK(ctx, hipGetLastError());
@@ -145,7 +146,7 @@ int pose_amd_create(int device, pose_amd_ctx **out)
     c->cus = prop.multiProcessorCount;
     c->clock_khz = prop.clockRate;
     if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 6; ++i)
         if ((e = hipEventCreate(&c->ev[i])) != hipSuccess) return bail("hipEventCreate", e);
     // co-occurrence gain table of the advanced sampler (query_processor_advanced.cpp:391-392)
     std::vector<double> gain(MAXCAM + 1);
@@ -166,7 +167,7 @@ void pose_amd_destroy(pose_amd_ctx *c)
                        &c->sample_status, &c->proj, &c->pose, &c->nsol, &c->counts, &c->sel, &c->bitmaps, &c->areas,
                        &c->maskw, &c->arows, &c->pstatus, &c->in0, &c->in1, &c->in2, &c->out0, &c->out1, &c->out2, &c->out3};
     for (dev_buf *b : bufs) if (b->p) (void)hipFree(b->p);
-    for (int i = 0; i < 4; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+    for (int i = 0; i < 6; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -582,6 +583,11 @@ int pose_amd_ransac_run(pose_amd_ctx *ctx, const pose_amd_params *prm, pose_amd_
         float ms;
         for (int i = 0; i < 3; ++i) { (void)hipEventElapsedTime(&ms, ctx->ev[i], ctx->ev[i + 1]); ctx->last_ms[i] += ms; }
         (void)hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[3]); ctx->last_ms[3] += ms;
+        if (ctx->solver == POSE_AMD_SOLVER_P4PF) {
+            (void)hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[4]); ctx->last_ms[4] += ms;
+            (void)hipEventElapsedTime(&ms, ctx->ev[4], ctx->ev[1]); ctx->last_ms[5] += ms;
+        }
+        ctx->last_ms[6] += 1.0f;
         steps += chunk_steps;
         if (chunk_best >= 0) {
             best_slot = (long long)h0 * maxsol + chunk_best;
@@ -625,7 +631,7 @@ int pose_amd_best_mask(pose_amd_ctx *ctx, uint8_t *mask)
     return POSE_AMD_OK;
 }
 
-int pose_amd_last_timing(pose_amd_ctx *ctx, float ms[4])
+int pose_amd_last_timing(pose_amd_ctx *ctx, float ms[8])
 {
     if (!ctx || !ms) return POSE_AMD_EINVAL;
     memcpy(ms, ctx->last_ms, sizeof ctx->last_ms);
