@@ -57,21 +57,20 @@ def main():
         print("bench.py: --gpus > 1 must be launched through torch.distributed.run", file=sys.stderr)
         return 2
 
-    from pose_estimation_amd import Context, synth, SELECT_INLIERS, SAMPLE_BASIC
+    from pose_estimation_amd import Context, shard, synth, SELECT_INLIERS, SAMPLE_BASIC
     ctx = Context(local_rank)
     q = synth.make_query(args.matches, args.inlier_frac, seed=2)
     ctx.set_query(q["kx"], q["ky"], q["X"], q["Y"], q["Z"], q["width"], q["height"], 0.0)
     H = args.hyps
-    key_t = torch.zeros(1, dtype=torch.int64, device=f"cuda:{local_rank}") if world > 1 else None
 
     def step(i):
         # hypothesis ids are global: rank r owns [ (i*world + r) * H, +H )
         ctx.sample(SAMPLE_BASIC, 1002, 0, ((i * world + rank) * H) % (1 << 31), H, export=False)
         r = ctx.ransac_run(SELECT_INLIERS, 0.5, early_exit=False)
         if world > 1:
-            gh = (i * world + rank) * H + r["best_hyp"]
-            key_t[0] = (int(r["inliers"]) << 32) | (0xFFFFFFFF - (gh & 0xFFFFFFFF))
-            dist.all_reduce(key_t, op=dist.ReduceOp.MAX)
+            # the only exchange of the hypothesis-sharded path: one packed (count, id) key
+            gh = ((i * world + rank) * H + r["best_hyp"]) & shard.KEY_ID_MASK
+            r["global_best"] = shard.unpack_key(shard.reduce_best(shard.pack_key(r["inliers"], gh), dist, f"cuda:{local_rank}"))
         return r
 
     def sync():

@@ -367,3 +367,43 @@ def test_query_processor_advanced_process(ctx):
                  select_coverage=True, early_exit=False, max_steps=100)
     assert np.linalg.norm(q.camera_position() - o["C"]) < 1e-6 * max(1.0, np.linalg.norm(o["C"]))
     assert np.linalg.norm(q.camera_position() - d["C_true"]) < 0.5
+
+
+# ---- committed loop fixtures -----------------------------------------------------------------
+def test_ransac_trace_fixture(ctx):
+    """Running best of the sequential loop after every step, from the committed fixture."""
+    with open(os.path.join(GOLD, "ransac_trace.json")) as f:
+        fx = json.load(f)
+    for e in fx:
+        f32 = lambda k: np.array(e[k], dtype=np.float32)   # noqa: E731
+        ctx.set_query(f32("kx"), f32("ky"), f32("X"), f32("Y"), f32("Z"), e["width"], e["height"], e["focal"])
+        samples = np.array(e["samples"], np.uint32)
+        for name, select in (("inliers", SELECT_INLIERS), ("coverage", SELECT_COVERAGE)):
+            tr = e["trace"][name]
+            for steps in range(1, len(samples) + 1):
+                ctx.set_samples(samples[:steps])
+                r = ctx.ransac_run(select, 0.5, early_exit=False)
+                found, step, sol, count, area = tr["running_best"][steps - 1]
+                assert r["found"] == found
+                if found:
+                    assert (r["best_hyp"], r["inliers"]) == (step, count), (name, steps)
+                    if select == SELECT_COVERAGE:
+                        assert r["area_fit"] == area
+            ctx.set_samples(samples)
+            r = ctx.ransac_run(select, 0.5, early_exit=True)
+            found, nsteps, step, sol, count, area = tr["early_exit"]
+            assert (r["found"], r["steps"]) == (found, nsteps)
+            if found:
+                assert (r["best_hyp"], r["inliers"]) == (step, count)
+            if select == SELECT_COVERAGE:
+                assert r["area_all"] == tr["area_all"]
+
+
+def test_advanced_sampler_fixture(ctx):
+    with open(os.path.join(GOLD, "advanced_samples.json")) as f:
+        fx = json.load(f)
+    q = synth.make_query(fx["n"], 0.5, 41)
+    upload(ctx, q)
+    ctx.set_camsets(np.array(fx["cam_off"], np.uint32), np.array(fx["cam_ids"], np.uint32))
+    got = ctx.sample(SAMPLE_ADVANCED, fx["seed"], fx["query_id"], 0, len(fx["tuples"]))
+    assert got.tolist() == fx["tuples"]

@@ -235,3 +235,39 @@ def test_ransac_loop_recovers_pose(known_focal):
         assert np.linalg.norm(r["C"] - q["C_true"]) < 0.5
         assert abs(r["focal"] - q["f_true"]) / q["f_true"] < 0.02
         assert r["mask"].sum() == r["hyposet"]
+
+
+# ---- committed loop fixtures ---------------------------------------------------------------
+def fixture_query(e):
+    f32 = lambda k: np.array(e[k], dtype=np.float32)   # noqa: E731
+    return dict(kx=f32("kx"), ky=f32("ky"), X=f32("X"), Y=f32("Y"), Z=f32("Z"), width=e["width"], height=e["height"],
+                focal=e["focal"])
+
+
+def test_ransac_trace_fixture():
+    with open(os.path.join(GOLD, "ransac_trace.json")) as f:
+        fx = json.load(f)
+    for e in fx:
+        q = fixture_query(e)
+        samples = np.array(e["samples"], np.uint32)
+        args = (q["kx"], q["ky"], q["X"], q["Y"], q["Z"], q["width"], q["height"], q["focal"])
+        for name, cov in (("inliers", False), ("coverage", True)):
+            tr = e["trace"][name]
+            for steps in (1, 2, 5, 17, 33, len(samples)):
+                r = O.ransac(*args, samples[:steps], select_coverage=cov, early_exit=False, max_steps=steps)
+                assert [r["found"], r["best_step"], r["best_sol"], r["hyposet"], r["area_fit"]] == tr["running_best"][steps - 1]
+            r = O.ransac(*args, samples, select_coverage=cov, early_exit=True, max_steps=len(samples))
+            assert [r["found"], r["steps"], r["best_step"], r["best_sol"], r["hyposet"], r["area_fit"]] == tr["early_exit"]
+            assert r["area_all"] == tr["area_all"]
+            # the running best only ever improves, and never by a tie (strict '>' at basic.cpp:214)
+            key = [(t[4] if cov else t[3]) for t in tr["running_best"]]
+            assert all(b >= a for a, b in zip(key, key[1:]))
+
+
+def test_advanced_sampler_fixture():
+    with open(os.path.join(GOLD, "advanced_samples.json")) as f:
+        fx = json.load(f)
+    off, ids = np.array(fx["cam_off"], np.uint32), np.array(fx["cam_ids"], np.uint32)
+    for h, (t, st, npr) in enumerate(zip(fx["tuples"], fx["status"], fx["prob_draws"])):
+        got, gst, gnp = O.sample_advanced(fx["seed"], fx["query_id"], h, 4, fx["n"], off, ids)
+        assert [int(v) for v in got] == t and gst == st and gnp == npr

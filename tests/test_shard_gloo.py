@@ -1,0 +1,44 @@
+"""Multi-process (world size 2, gloo, CPU) check of the hypothesis-range and query partitions."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+from pose_estimation_amd import shard
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def test_hypothesis_shard_covers_range():
+    for total in (0, 1, 7, 96, 1 << 20):
+        for world in (1, 2, 3, 8):
+            parts = [shard.hypothesis_shard(total, r, world) for r in range(world)]
+            assert parts[0][0] == 0 and parts[-1][1] == total
+            assert all(parts[i][1] == parts[i + 1][0] for i in range(world - 1))
+            sizes = [e - b for b, e in parts]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_key_order_is_the_sequential_rule():
+    # more inliers wins; equal counts: the earlier hypothesis (strict '>' in the loop)
+    assert shard.pack_key(10, 500) > shard.pack_key(9, 0)
+    assert shard.pack_key(10, 3) > shard.pack_key(10, 4)
+    assert shard.unpack_key(shard.pack_key(123, 456789)) == (123, 456789)
+    assert shard.pack_key(0, 0) > 0
+
+
+def test_two_ranks_agree_with_sequential_loop(tmp_path):
+    out = tmp_path / "result.json"
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(HERE, "gloo_worker.py"), str(out)]
+    subprocess.run(cmd, check=True, env=env, timeout=600, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    r = json.loads(out.read_text())
+    assert r["world"] == 2
+    assert (r["count"], r["hyp"]) == (r["ref_count"], r["ref_hyp"]) and r["count"] > 0
+    assert r["queries_ok"]
+    assert abs(r["loads"][0] - r["loads"][1]) <= 0.02 * sum(r["loads"])

@@ -9,6 +9,13 @@ oracle, so it pins the oracle's comparison independently.
 
 p4pf_lapack.json: 40 random P4Pf problems with the roots (f, zb, zc, zd) obtained from the
 NumPy/LAPACK restatement in tests/np_ref.py.
+
+ransac_trace.json: two small queries (P4Pf and P3P) with an explicit list of sample tuples and
+the oracle's running best after every step of the sequential loop (query_processor_basic.cpp:
+132-228) for both selection rules, plus the early-exit end state.
+
+advanced_samples.json: a small query with camera sets and the tuples the co-occurrence sampler
+(query_processor_advanced.cpp:329-440) draws from fixed counter-based random streams.
 """
 import json
 import os
@@ -82,9 +89,48 @@ def p4pf_fixture():
     return out
 
 
+def trace_fixture():
+    out = []
+    for known in (False, True):
+        q = synth.make_query(160, 0.45, 31 + known, known_focal=known)
+        m = 3 if known else 4
+        n = len(q["kx"])
+        K = 60
+        samples = np.array([O.sample_basic(5, 0, h, m, n)[0] for h in range(K)], np.uint32)
+        args = (q["kx"], q["ky"], q["X"], q["Y"], q["Z"], q["width"], q["height"], q["focal"])
+        entry = dict(known_focal=bool(known), width=q["width"], height=q["height"], focal=float(q["focal"]),
+                     kx=q["kx"].tolist(), ky=q["ky"].tolist(), X=q["X"].tolist(), Y=q["Y"].tolist(), Z=q["Z"].tolist(),
+                     samples=samples.tolist(), trace={})
+        for cov in (False, True):
+            tr = []
+            for steps in range(1, K + 1):
+                r = O.ransac(*args, samples[:steps], select_coverage=cov, early_exit=False, max_steps=steps)
+                tr.append([int(r["found"]), int(r["best_step"]), int(r["best_sol"]), int(r["hyposet"]), int(r["area_fit"])])
+            e = O.ransac(*args, samples, select_coverage=cov, early_exit=True, max_steps=K)
+            entry["trace"]["coverage" if cov else "inliers"] = dict(
+                running_best=tr, early_exit=[int(e["found"]), int(e["steps"]), int(e["best_step"]), int(e["best_sol"]),
+                                             int(e["hyposet"]), int(e["area_fit"])], area_all=int(e["area_all"]))
+        out.append(entry)
+    return out
+
+
+def advanced_fixture():
+    q = synth.make_query(90, 0.5, 41)
+    synth.add_camsets(q, seed=43)
+    n = len(q["kx"])
+    tuples, status, probs = [], [], []
+    for h in range(48):
+        t, st, npr = O.sample_advanced(9, 3, h, 4, n, q["cam_off"], q["cam_ids"])
+        tuples.append([int(v) for v in t]); status.append(int(st)); probs.append(int(npr))
+    return dict(n=n, seed=9, query_id=3, cam_off=q["cam_off"].tolist(), cam_ids=q["cam_ids"].tolist(), tuples=tuples,
+                status=status, prob_draws=probs)
+
+
 if __name__ == "__main__":
     gd = os.path.join(ROOT, "tests", "golden")
     os.makedirs(gd, exist_ok=True)
     json.dump(score_fixture(), open(os.path.join(gd, "score_threshold.json"), "w"))
     json.dump(p4pf_fixture(), open(os.path.join(gd, "p4pf_lapack.json"), "w"))
+    json.dump(trace_fixture(), open(os.path.join(gd, "ransac_trace.json"), "w"))
+    json.dump(advanced_fixture(), open(os.path.join(gd, "advanced_samples.json"), "w"))
     print("fixtures written")
