@@ -7,7 +7,9 @@ HDRS := $(wildcard $(CSRC)/*.h) include/pose_amd.h
 
 SHIM := tests/host_shim/libhost_eig.so
 
-all: $(LIB) oracle $(SHIM)
+FACADE_TEST := tests/cpp/facade_test
+
+all: $(LIB) oracle $(SHIM) $(FACADE_TEST)
 
 $(LIB): $(CSRC)/pose_amd.hip $(HDRS)
 	$(HIPCC) -O3 -std=c++17 --offload-arch=$(ARCH) -fPIC -shared -Wall -Wno-unused-function -o $@ $<
@@ -16,11 +18,15 @@ $(LIB): $(CSRC)/pose_amd.hip $(HDRS)
 $(SHIM): tests/host_shim/eig_shim.hip $(HDRS)
 	$(HIPCC) -O2 -std=c++17 --offload-arch=$(ARCH) -fPIC -shared -Wno-unused-function -o $@ $<
 
+# Test driver of the C++ host facade (plain g++, links the library through its C ABI).
+$(FACADE_TEST): tests/cpp/facade_test.cpp include/pose_amd.hpp include/pose_amd.h $(LIB)
+	g++ -std=c++17 -O1 -Wall -Iinclude $< -o $@ -Lpose_estimation_amd -lpose_amd -Wl,-rpath,'$$ORIGIN/../../pose_estimation_amd'
+
 oracle:
 	$(MAKE) -C oracle
 
 clean:
-	rm -f $(LIB) $(SHIM)
+	rm -f $(LIB) $(SHIM) $(FACADE_TEST)
 	$(MAKE) -C oracle clean
 
 .PHONY: all oracle clean

@@ -1,0 +1,329 @@
+// C++ host facade over the C ABI of libpose_amd (include/pose_amd.h).
+//
+// It keeps the class interface the reference's host code is written against, so that the
+// reference's call sites compile unchanged once its solver/processor headers are replaced:
+//   P3p::computePoses / solveQuartic                     (P3p.hpp:59-60)
+//   P4pf::P4Pf_m / P4Pf                                  (P4pf.hpp:39-41)
+//   QueryProcessor::TestHypothesis, QueryProcessorBasic/Advanced::Process
+//                                                        (query_processor.hpp:33-73)
+// The reference passes Eigen matrices by value; Eigen is not a dependency here, so the small
+// fixed-size type Mat<R,C> below is used instead.  It is column-major and contiguous like
+// Eigen::Matrix<double,R,C>, so an Eigen build can construct it from `m.data()`.
+//
+// Error behaviour follows the reference: the solvers return 0 / -1 and never throw; Process
+// always returns true.  A missing GPU or a failed HIP call is not a reference condition: it
+// throws std::runtime_error carrying pose_amd_last_error().  There is no CPU fallback.
+#pragma once
+#include <algorithm>
+#include <cstdint>
+#include <cstring>
+#include <set>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "pose_amd.h"
+
+namespace pose_estimation_amd {
+
+template <int R, int C>
+struct Mat {
+    double v[R * C];
+    Mat() { std::memset(v, 0, sizeof v); }
+    explicit Mat(const double *colmajor) { std::memcpy(v, colmajor, sizeof v); }
+    double &operator()(int r, int c) { return v[c * R + r]; }
+    double operator()(int r, int c) const { return v[c * R + r]; }
+    double *data() { return v; }
+    const double *data() const { return v; }
+};
+using Matrix3d = Mat<3, 3>;
+using Vector3d = Mat<3, 1>;
+
+// One context per device, created on first use (the reference creates one solver object per
+// Process call, basic.cpp:100-101; contexts are heavier, so they are shared per thread).
+class Device {
+public:
+    explicit Device(int index = 0)
+    {
+        if (pose_amd_create(index, &ctx_) != POSE_AMD_OK) throw std::runtime_error(std::string("pose_amd_create: ") + pose_amd_last_error(nullptr));
+    }
+    ~Device() { if (ctx_) pose_amd_destroy(ctx_); }
+    Device(const Device &) = delete;
+    Device &operator=(const Device &) = delete;
+    pose_amd_ctx *ctx() const { return ctx_; }
+    void check(int rc, const char *what) const
+    {
+        if (rc != POSE_AMD_OK) throw std::runtime_error(std::string(what) + ": " + pose_amd_last_error(ctx_));
+    }
+    static Device &current()
+    {
+        static thread_local Device dev(0);
+        return dev;
+    }
+
+private:
+    pose_amd_ctx *ctx_ = nullptr;
+};
+
+// ---- P3p.hpp:54-61 ----------------------------------------------------------------------------
+class P3p {
+public:
+    explicit P3p(Device *dev = nullptr) : dev_(dev ? dev : &Device::current()) {}
+    // featureVectors, worldPoints: one vector per column.  solutions: 4 blocks [C | R].
+    int computePoses(Mat<3, 3> featureVectors, Mat<3, 3> worldPoints, Mat<3, 16> &solutions)
+    {
+        int status = 0;
+        double sol[48];
+        // the ABI takes one vector after the other = the columns of a column-major matrix
+        dev_->check(pose_amd_p3p_batch(dev_->ctx(), 1, featureVectors.data(), worldPoints.data(), sol, &status), "p3p_batch");
+        if (status != 0) return -1;
+        for (int i = 0; i < 4; ++i) {
+            const double *s = sol + 12 * i;      // C[3], Rc[9] row-major
+            for (int r = 0; r < 3; ++r) {
+                solutions(r, 4 * i) = s[r];
+                for (int c = 0; c < 3; ++c) solutions(r, 4 * i + 1 + c) = s[3 + 3 * r + c];
+            }
+        }
+        return 0;
+    }
+    int solveQuartic(Mat<5, 1> factors, Mat<4, 1> &realRoots)
+    {
+        dev_->check(pose_amd_quartic_batch(dev_->ctx(), 1, factors.data(), realRoots.data()), "quartic_batch");
+        return 0;
+    }
+
+private:
+    Device *dev_;
+};
+
+// ---- P4pf.hpp:28-59 ---------------------------------------------------------------------------
+class P4pf {
+public:
+    explicit P4pf(Device *dev = nullptr) : dev_(dev ? dev : &Device::current()) {}
+    // m2D: 2x4 image points (centred), M3D: 3x4 world points; results are appended.
+    int P4Pf_m(Mat<2, 4> m2D, Mat<3, 4> M3D, std::vector<double> *focalLengths_m, std::vector<Matrix3d> *rotationMatrices,
+               std::vector<Vector3d> *translationResult)
+    {
+        int nsol = 0;
+        double f[POSE_AMD_P4PF_MAXSOL], R[9 * POSE_AMD_P4PF_MAXSOL], t[3 * POSE_AMD_P4PF_MAXSOL];
+        dev_->check(pose_amd_p4pf_batch(dev_->ctx(), 1, m2D.data(), M3D.data(), &nsol, f, R, t), "p4pf_batch");
+        if (nsol < 0) return -1;
+        for (int i = 0; i < nsol; ++i) {
+            focalLengths_m->push_back(f[i]);
+            Matrix3d Ri;
+            for (int r = 0; r < 3; ++r)
+                for (int c = 0; c < 3; ++c) Ri(r, c) = R[9 * i + 3 * r + c];
+            rotationMatrices->push_back(Ri);
+            translationResult->push_back(Vector3d(t + 3 * i));
+        }
+        return 0;
+    }
+    // The reference's Gauss-Jordan variant solves the same system (P4pf.cpp:558-854).
+    int P4Pf(Mat<2, 4> m2D, Mat<3, 4> M3D, std::vector<double> *f, std::vector<Matrix3d> *R, std::vector<Vector3d> *t)
+    {
+        return P4Pf_m(m2D, M3D, f, R, t);
+    }
+
+private:
+    Device *dev_;
+};
+
+// ---- correspondence records (query_processor.hpp:20-31, SIFT_keypoint.hpp:35-55, parse_bundler.hpp:52-97)
+struct SiftMatch {
+    unsigned int lindex = 0;    // query keypoint
+    unsigned int mindex = 0;    // 3D point
+    float distance = 0.0f;
+    std::set<unsigned int> camset;
+};
+struct SIFT_keypoint { float x = 0, y = 0, scale = 0, orientation = 0; };
+struct point3D { float x = 0, y = 0, z = 0; };
+struct feature_3D_info { point3D point; };
+
+// The pose-related part of query_loader.hpp:30-75.
+class Query {
+public:
+    Query(int width, int height, double focal_length = 0.0) : focal_(focal_length), w_(width), h_(height)
+    {
+        rot_(0, 0) = rot_(1, 1) = rot_(2, 2) = 1.0;
+    }
+    double focal_length() const { return focal_; }
+    Vector3d camera_position() const { return pos_; }
+    Matrix3d camera_rotation() const { return rot_; }
+    Mat<3, 4> proj_matrix() const { return proj_; }
+    void set_camera_position(Vector3d p) { pos_ = p; }
+    void set_camera_rotation(Matrix3d r) { rot_ = r; }
+    void set_focal_length(double f) { focal_ = f; }
+    int image_width() const { return w_; }
+    int image_height() const { return h_; }
+    std::vector<SIFT_keypoint> &sift_keypoints() { return keys_; }
+    // query_loader.cpp:222-254
+    bool ComputeMatrices(Device *dev = nullptr)
+    {
+        Device *d = dev ? dev : &Device::current();
+        double Rc[9], P[12];
+        for (int r = 0; r < 3; ++r)
+            for (int c = 0; c < 3; ++c) Rc[3 * r + c] = rot_(r, c);
+        d->check(pose_amd_compute_matrices_batch(d->ctx(), 1, &focal_, pos_.data(), Rc, P), "compute_matrices_batch");
+        for (int r = 0; r < 3; ++r)
+            for (int c = 0; c < 4; ++c) proj_(r, c) = P[4 * r + c];
+        return true;
+    }
+
+private:
+    double focal_;
+    Vector3d pos_;
+    Matrix3d rot_;
+    Mat<3, 4> proj_;
+    std::vector<SIFT_keypoint> keys_;
+    int w_, h_;
+};
+
+// ---- query_processor.hpp:33-73 ------------------------------------------------------------------
+// The matching stage that precedes RANSAC in the reference's Process (FLANN search) is not part
+// of this library: Process takes the `good_matches` list the reference has at basic.cpp:105 /
+// advanced.cpp:296 together with the 3D points they refer to.
+class QueryProcessor {
+public:
+    explicit QueryProcessor(Device *dev = nullptr) : dev_(dev ? dev : &Device::current()) {}
+    virtual ~QueryProcessor() {}
+    virtual bool Process(Query &query, std::vector<SiftMatch> &good_matches, std::vector<feature_3D_info> &sifts) = 0;
+
+    // Inliers of query.proj_matrix() among `matches` and the coverage quality (query_processor.cpp:88-177).
+    std::vector<SiftMatch> TestHypothesis(Query &query, std::vector<SiftMatch> &matches, std::vector<SIFT_keypoint> &sift_keypoints,
+                                          std::vector<feature_3D_info> &sifts, double match_eps, double &fit_quality)
+    {
+        solver_focal_ = query.focal_length();
+        upload(query, matches, sift_keypoints, sifts, false);
+        const int n = (int)matches.size();
+        const Mat<3, 4> Pm = query.proj_matrix();
+        double P[12];
+        for (int r = 0; r < 3; ++r)
+            for (int c = 0; c < 4; ++c) P[4 * r + c] = Pm(r, c);
+        int count = 0;
+        std::vector<uint64_t> words((size_t)(n + 63) / 64);
+        dev_->check(pose_amd_score_batch(dev_->ctx(), 1, P, match_eps, &count, words.data()), "score_batch");
+        int64_t area = 0, area_all = 0;
+        dev_->check(pose_amd_coverage_batch(dev_->ctx(), 1, P, match_eps, &area, &area_all), "coverage_batch");
+        fit_quality = (double)((float)area / (float)area_all);
+        std::vector<SiftMatch> fitted;
+        for (int i = 0; i < n; ++i)
+            if ((words[(size_t)i >> 6] >> (i & 63)) & 1u) fitted.push_back(matches[(size_t)i]);
+        return fitted;
+    }
+
+    // what the last Process consumed / produced, for parity checks on identical samples
+    std::vector<uint32_t> samples;          // 4 indices per step
+    pose_amd_result result{};
+    std::vector<SiftMatch> fitted_matches;
+
+protected:
+    void upload(Query &query, std::vector<SiftMatch> &matches, std::vector<SIFT_keypoint> &keys, std::vector<feature_3D_info> &sifts,
+                bool camsets)
+    {
+        const size_t n = matches.size();
+        std::vector<float> kx(n), ky(n), X(n), Y(n), Z(n);
+        std::vector<uint32_t> lindex(n), off(n + 1, 0), ids;
+        for (size_t i = 0; i < n; ++i) {
+            const SiftMatch &m = matches[i];
+            kx[i] = keys[m.lindex].x; ky[i] = keys[m.lindex].y;
+            const point3D &p = sifts[m.mindex].point;
+            X[i] = p.x; Y[i] = p.y; Z[i] = p.z;
+            lindex[i] = m.lindex;
+            if (camsets) ids.insert(ids.end(), m.camset.begin(), m.camset.end());
+            off[i + 1] = (uint32_t)ids.size();
+        }
+        dev_->check(pose_amd_set_query(dev_->ctx(), (int)n, kx.data(), ky.data(), X.data(), Y.data(), Z.data(), lindex.data(),
+                                       query.image_width(), query.image_height(), solver_focal_),
+                    "set_query");
+        if (camsets) dev_->check(pose_amd_set_camsets(dev_->ctx(), off.data(), ids.data()), "set_camsets");
+    }
+
+    // sample `steps` tuples, run the loop, store the kept pose in `query`
+    bool run(Query &query, std::vector<SiftMatch> &matches, int sample_mode, uint32_t hyp_begin, uint32_t steps, int early_exit)
+    {
+        const size_t old = samples.size();
+        samples.resize(old + (size_t)steps * 4);
+        dev_->check(pose_amd_sample(dev_->ctx(), sample_mode, seed, query_id, hyp_begin, steps, samples.data() + old), "sample");
+        pose_amd_params prm;
+        std::memset(&prm, 0, sizeof prm);
+        prm.select_mode = select_mode; prm.eps = inlier_eps; prm.early_exit = early_exit;
+        prm.inlier_divisor = inlier_divisor; prm.inlier_absolute = inlier_absolute;
+        pose_amd_result r;
+        dev_->check(pose_amd_ransac_run(dev_->ctx(), &prm, &r, nullptr, nullptr), "ransac_run");
+        const bool better = r.found && (!result.found || (select_mode == POSE_AMD_SELECT_COVERAGE
+                                                              ? (float)r.area_fit / (float)r.area_all > (float)result.area_fit / (float)result.area_all
+                                                              : r.inliers > result.inliers));
+        r.steps += result.steps;
+        if (!better) { result.steps = r.steps; return false; }
+        result = r;
+        std::vector<uint8_t> mask(matches.size());
+        dev_->check(pose_amd_best_mask(dev_->ctx(), mask.data()), "best_mask");
+        fitted_matches.clear();
+        for (size_t i = 0; i < matches.size(); ++i)
+            if (mask[i]) fitted_matches.push_back(matches[i]);
+        if (solver_focal_ == 0.0) query.set_focal_length(r.focal);      // unknown focal: the P4Pf estimate
+        query.set_camera_position(Vector3d(r.C));
+        Matrix3d Rc;
+        for (int a = 0; a < 3; ++a)
+            for (int b = 0; b < 3; ++b) Rc(a, b) = r.Rc[3 * a + b];
+        query.set_camera_rotation(Rc);
+        return true;
+    }
+
+public:
+    // RANSAC parameters (basic.cpp:107-119) and the stream of the counter-based generator that
+    // replaces the time-seeded mt19937_64 (pose_utils.cpp:58-84)
+    double inlier_eps = 0.5;
+    uint32_t inlier_divisor = 10, inlier_absolute = 12;
+    int select_mode = POSE_AMD_SELECT_COVERAGE;
+    uint64_t seed = 0;
+    uint32_t query_id = 0;
+
+protected:
+    Device *dev_;
+    double solver_focal_ = 0.0;             // focal length the query came with: 0 selects P4Pf (basic.cpp:154)
+};
+
+class QueryProcessorBasic : public QueryProcessor {
+public:
+    using QueryProcessor::QueryProcessor;
+    uint32_t max_ransac_steps = 10000;
+    // query_processor_basic.cpp:105-293
+    bool Process(Query &query, std::vector<SiftMatch> &good_matches, std::vector<feature_3D_info> &sifts) override
+    {
+        samples.clear(); fitted_matches.clear(); std::memset(&result, 0, sizeof result);
+        solver_focal_ = query.focal_length();
+        upload(query, good_matches, query.sift_keypoints(), sifts, false);
+        run(query, good_matches, POSE_AMD_SAMPLE_BASIC, 0, max_ransac_steps, 1);
+        samples.resize((size_t)result.steps * 4);
+        query.ComputeMatrices(dev_);
+        return true;
+    }
+};
+
+class QueryProcessorAdvanced : public QueryProcessor {
+public:
+    using QueryProcessor::QueryProcessor;
+    uint32_t max_ransac_steps = 100;
+    // Stand-in for QueryProcessorAdvanced::Backmatching (advanced.cpp:75-237, a FLANN search
+    // outside this library): may append matches; return false to skip.
+    bool (*backmatching)(std::vector<SiftMatch> &good_matches, void *user) = nullptr;
+    void *backmatching_user = nullptr;
+    // query_processor_advanced.cpp:296-606
+    bool Process(Query &query, std::vector<SiftMatch> &good_matches, std::vector<feature_3D_info> &sifts) override
+    {
+        samples.clear(); fitted_matches.clear(); std::memset(&result, 0, sizeof result);
+        solver_focal_ = query.focal_length();
+        upload(query, good_matches, query.sift_keypoints(), sifts, true);
+        run(query, good_matches, POSE_AMD_SAMPLE_ADVANCED, 0, max_ransac_steps, 0);
+        const uint32_t thresh = std::min<uint32_t>((uint32_t)good_matches.size() / inlier_divisor, inlier_absolute);
+        if (backmatching && (result.found ? result.inliers : 0u) < thresh && backmatching(good_matches, backmatching_user)) {
+            upload(query, good_matches, query.sift_keypoints(), sifts, true);
+            run(query, good_matches, POSE_AMD_SAMPLE_ADVANCED, max_ransac_steps, max_ransac_steps, 0);
+        }
+        query.ComputeMatrices(dev_);
+        return true;
+    }
+};
+
+} // namespace pose_estimation_amd

@@ -1,0 +1,165 @@
+// Exercises the C++ host facade (include/pose_amd.hpp) the way the reference's own test
+// drivers exercise its classes (p3p_testing.cpp:40-65, p4p_testing.cpp:49-110), then runs the
+// two processors on a synthetic query with a planted pose.  Exit status 0 = all checks passed.
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <random>
+
+#include "pose_amd.hpp"
+
+using namespace pose_estimation_amd;
+
+static int failures = 0;
+#define CHECK(cond)                                                          \
+    do {                                                                     \
+        if (!(cond)) { std::printf("FAILED %s:%d: %s\n", __FILE__, __LINE__, #cond); ++failures; } \
+    } while (0)
+
+static void test_p3p()
+{
+    // p3p_testing.cpp:40-53
+    const double pts[9] = {0.0, 0.0, 1.0, 10.5, 10.5, 10.5, -10.5, -9.5, -9.5};                // one point per row
+    const double fts[9] = {-0.049875, -0.049875, 0.049875, 0.049875, -0.049875, -0.049875, 0.99751, 0.99751, 0.99751};
+    Mat<3, 3> worldPoints, featureVectors;
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) { worldPoints(r, c) = pts[3 * r + c]; featureVectors(r, c) = fts[3 * r + c]; }
+    const double golden[48] = {
+        1.7739, 0.9917, 0.0064, -0.1281, 0.5665, 1.0000, 0.0003, -0.0066, 0.1272, 0.9993, -0.0019, 0.0372, -0.4751, 0.9952,
+        -0.0049, 0.0977, 0.6782, 0.1283, -0.0356, 0.9911, 0.5227, 0.0066, -0.0059, 1.0000, 0.7136, -0.0366, 0.1435, 0.9890,
+        0.6218, -0.0977, -0.1019, 0.9900, -9.6385, 0.0018, -0.9994, -0.0361, -9.9416, 0.0003, -1.0000, -0.0059, -11.4235,
+        -0.0072, -0.9896, 0.1434, -8.9839, 0.0051, -0.9948, -0.1019};
+    P3p p3p;
+    Mat<3, 16> sol;
+    CHECK(p3p.computePoses(featureVectors, worldPoints, sol) == 0);
+    double err = 0;
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 16; ++c) { const double d = sol(r, c) - golden[16 * r + c]; err += d * d; }
+    CHECK(std::sqrt(err) < 0.15);                  // p3p_testing.cpp:65
+    Mat<3, 3> collinear;
+    for (int c = 0; c < 3; ++c)
+        for (int r = 0; r < 3; ++r) collinear(r, c) = c;
+    CHECK(p3p.computePoses(featureVectors, collinear, sol) == -1);
+}
+
+static void test_p4pf()
+{
+    // p4p_testing.cpp:49-70
+    const double M[12] = {-3.33639834336120, -23.35549638285873, -13.18941519576778, 6.43164913914748,
+                          0.65948286155096, -4.90376715918747, 1.17103701629876, 0.14580433383203,
+                          -8.46658219501120, -3.99876939947909, -3.02248927651177, -22.16086539862748};
+    const double m[8] = {0.11009888473695, 0.39776592879400, 0.28752996253253, -0.05017617729940,
+                         0.03882059658299, -0.17303453640632, -0.05791310109713, 0.19297848817239};
+    Mat<3, 4> M3D;
+    Mat<2, 4> m2D;
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 4; ++c) M3D(r, c) = M[4 * r + c];
+    for (int r = 0; r < 2; ++r)
+        for (int c = 0; c < 4; ++c) m2D(r, c) = m[4 * r + c];
+    P4pf p4pf;
+    std::vector<double> f;
+    std::vector<Matrix3d> R;
+    std::vector<Vector3d> t;
+    f.push_back(-1.0);                              // results are appended, never overwritten
+    R.push_back(Matrix3d());
+    t.push_back(Vector3d());
+    CHECK(p4pf.P4Pf_m(m2D, M3D, &f, &R, &t) == 0);
+    CHECK(f.size() >= 2 && f.size() == R.size() && f.size() == t.size() && f[0] == -1.0);
+    double best = 1e9;
+    size_t bi = 0;
+    for (size_t i = 1; i < f.size(); ++i)
+        if (std::fabs(f[i] - 1.5) < best) { best = std::fabs(f[i] - 1.5); bi = i; }
+    CHECK(best < 1e-9);
+    const double tgt[3] = {2.85817409844554, -2.17296255562889, 77.54246130780075};
+    double terr = 0;
+    for (int k = 0; k < 3; ++k) terr += (t[bi](k, 0) - tgt[k]) * (t[bi](k, 0) - tgt[k]);
+    CHECK(std::sqrt(terr) < 1e-7);
+    CHECK(std::fabs(R[bi](0, 0) + 0.94382954756954) < 1e-9 && std::fabs(R[bi](1, 2) + 0.56276540799790) < 1e-9);
+    // degenerate: two identical world points (P4pf.cpp:343-346)
+    for (int r = 0; r < 3; ++r) M3D(r, 1) = M3D(r, 0);
+    std::vector<double> f2;
+    std::vector<Matrix3d> R2;
+    std::vector<Vector3d> t2;
+    CHECK(p4pf.P4Pf_m(m2D, M3D, &f2, &R2, &t2) == -1 && f2.empty());
+}
+
+struct Scene {
+    Query query;
+    std::vector<SiftMatch> matches;
+    std::vector<feature_3D_info> sifts;
+    double Ctrue[3];
+    Scene(int w, int h, double focal) : query(w, h, focal) {}
+};
+
+// n matches, the first `inl` consistent with a camera at Ctrue looking down +Z (Rc = I)
+static Scene make_scene(int n, int inl, bool known_focal, unsigned seed)
+{
+    const int w = 1600, h = 1200;
+    const double f = 1200.0;
+    Scene s(w, h, known_focal ? f : 0.0);
+    s.Ctrue[0] = 3.0; s.Ctrue[1] = -2.0; s.Ctrue[2] = 1.0;
+    std::mt19937 rng(seed);
+    std::uniform_real_distribution<double> u(-1.0, 1.0);
+    for (int i = 0; i < n; ++i) {
+        const double z = 10.0 + 95.0 * (u(rng) + 1.0);
+        const double px = 0.45 * w * u(rng), py = 0.45 * h * u(rng);        // centred image coordinates, x right / y up
+        feature_3D_info p3;
+        p3.point.x = (float)(s.Ctrue[0] + px * z / f); p3.point.y = (float)(s.Ctrue[1] + py * z / f); p3.point.z = (float)(s.Ctrue[2] + z);
+        s.sifts.push_back(p3);
+        SIFT_keypoint k;
+        double ox = px, oy = py;
+        if (i >= inl) { ox = 0.5 * w * u(rng); oy = 0.5 * h * u(rng); }
+        // obs = -(k - w/2)  (query_processor.cpp:111-112)
+        k.x = (float)(w / 2.0 - ox); k.y = (float)(h / 2.0 - oy);
+        s.query.sift_keypoints().push_back(k);
+        SiftMatch m;
+        m.lindex = (unsigned)i; m.mindex = (unsigned)i; m.distance = 0.1f;
+        // camera sets: inliers share cameras 1..6, outliers see two random ones
+        if (i < inl) { for (unsigned c = 1; c <= 6; ++c) if ((i + c) % 3 != 0 || i % 7 == 0) m.camset.insert(c); if (i % 7 == 0) m.camset.insert(7); }
+        else { m.camset.insert(100 + (unsigned)(rng() % 500)); m.camset.insert(700 + (unsigned)(rng() % 500)); }
+        s.matches.push_back(m);
+    }
+    return s;
+}
+
+static void test_processors()
+{
+    for (int known = 0; known < 2; ++known) {
+        Scene s = make_scene(600, 240, known != 0, 5u + known);
+        QueryProcessorBasic basic;
+        basic.seed = 42;
+        CHECK(basic.Process(s.query, s.matches, s.sifts));
+        CHECK(basic.result.found == 1 && basic.result.inliers >= 12 && basic.result.steps < 10000);
+        CHECK(basic.samples.size() == (size_t)basic.result.steps * 4);
+        CHECK(basic.fitted_matches.size() == basic.result.inliers);
+        const Vector3d C = s.query.camera_position();
+        const double d = std::sqrt((C(0, 0) - 3.0) * (C(0, 0) - 3.0) + (C(1, 0) + 2.0) * (C(1, 0) + 2.0) + (C(2, 0) - 1.0) * (C(2, 0) - 1.0));
+        CHECK(d < 3.0);
+        CHECK(std::fabs(s.query.focal_length() - 1200.0) < 60.0);
+        // the kept pose, re-tested through TestHypothesis, gives back the same inliers
+        double q = 0;
+        std::vector<SiftMatch> again = basic.TestHypothesis(s.query, s.matches, s.query.sift_keypoints(), s.sifts, 0.5, q);
+        CHECK(again.size() == basic.fitted_matches.size() && q > 0.0 && q <= 1.0);
+
+        Scene a = make_scene(600, 240, known != 0, 9u + known);
+        QueryProcessorAdvanced adv;
+        adv.seed = 43;
+        CHECK(adv.Process(a.query, a.matches, a.sifts));
+        CHECK(adv.result.found == 1 && adv.result.steps == 100 && adv.samples.size() == 400);
+        CHECK(adv.result.inliers >= 100);           // co-occurrence sampling finds the planted cluster
+    }
+}
+
+int main()
+{
+    try {
+        test_p3p();
+        test_p4pf();
+        test_processors();
+    } catch (const std::exception &e) {
+        std::printf("EXCEPTION %s\n", e.what());
+        return 2;
+    }
+    std::printf(failures ? "%d check(s) failed\n" : "facade ok\n", failures);
+    return failures ? 1 : 0;
+}
