@@ -258,7 +258,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 // P4Pf, stage C: one hypothesis per lane.  Action matrix -> accepted roots -> (f, R, t).
 // With proj != null the solutions go to the pose slots of the RANSAC pipeline, otherwise to
 // the flat arrays of the batch entry point.
-__global__ void k_p4pf_finish(query_dev q, uint32_t hyp_count, const uint32_t *__restrict__ samples, const double *__restrict__ m2d_in,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_p4pf_finish(query_dev q, uint32_t hyp_count, const uint32_t *__restrict__ samples, const double *__restrict__ m2d_in,
                               const double *__restrict__ M3D_in, const double *__restrict__ Arows, const int *__restrict__ status,
                               double *__restrict__ proj, double *__restrict__ pose, int *__restrict__ nsol, double *__restrict__ fo,
                               double *__restrict__ Ro, double *__restrict__ to)

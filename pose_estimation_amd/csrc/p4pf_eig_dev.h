@@ -49,13 +49,26 @@ PA_HD void poly_eval2(const double (&c)[N + 1], double x, double &v, double &dv)
     for (int i = N - 1; i >= 0; --i) { dv = fma(dv, x, v); v = fma(v, x, c[i]); }
 }
 
+// Iteration budget and relative tolerance of the bracketed root refinement.  Critical points
+// of the derivative chain only delimit brackets and the sextic's roots are polished afterwards
+// on det P(L), so neither needs full precision.
+#ifndef P4PF_REFINE_ITS
+#define P4PF_REFINE_ITS 60
+#endif
+#ifndef P4PF_REFINE_TOL
+#define P4PF_REFINE_TOL 1e-6        // critical points (bracket ends)
+#endif
+#ifndef P4PF_REFINE_TOL_TOP
+#define P4PF_REFINE_TOL_TOP 1e-6    // roots of the sextic itself: cheap here, saves Newton steps on det P(L)
+#endif
+
 // Root of a degree-N polynomial inside a bracket [a, b] with p(a) p(b) < 0: Newton steps,
 // bisection whenever a step leaves the bracket.
 template <int N>
-PA_HD double poly_refine(const double (&c)[N + 1], double a, double b, double fa)
+PA_HD double poly_refine(const double (&c)[N + 1], double a, double b, double fa, double tol)
 {
     double x = 0.5 * (a + b);
-    for (int it = 0; it < 80; ++it) {
+    for (int it = 0; it < P4PF_REFINE_ITS; ++it) {
         double f, df;
         poly_eval2<N>(c, x, f, df);
         if (f == 0.0) return x;
@@ -64,7 +77,7 @@ PA_HD double poly_refine(const double (&c)[N + 1], double a, double b, double fa
         if (!(xn > a && xn < b)) xn = 0.5 * (a + b);
         const double step = fabs(xn - x);
         x = xn;
-        if (step <= 4e-16 * fmax(1.0, fabs(x)) || b - a <= 4e-16 * fmax(1.0, fabs(x))) break;
+        if (step <= tol * fmax(1.0, fabs(x)) || b - a <= tol * fmax(1.0, fabs(x))) break;
     }
     return x;
 }
@@ -73,7 +86,7 @@ PA_HD double poly_refine(const double (&c)[N + 1], double a, double b, double fa
 // not reported.  r[] entries beyond the returned count are unspecified.
 template <int N>
 struct poly_roots {
-    static PA_HD int find(const double (&c)[N + 1], double lo, double hi, double (&r)[N])
+    static PA_HD int find(const double (&c)[N + 1], double lo, double hi, double (&r)[N], double tol = P4PF_REFINE_TOL)
     {
         double d[N], crit[N - 1];
 #pragma unroll
@@ -87,7 +100,7 @@ struct poly_roots {
             const double fb = poly_eval<N>(c, b);
             double root = 0.0;
             bool have = false;
-            if (b > a && ((fa < 0.0 && fb > 0.0) || (fa > 0.0 && fb < 0.0))) { root = poly_refine<N>(c, a, b, fa); have = true; }
+            if (b > a && ((fa < 0.0 && fb > 0.0) || (fa > 0.0 && fb < 0.0))) { root = poly_refine<N>(c, a, b, fa, tol); have = true; }
             else if (fb == 0.0 && (k >= ncrit) && b > a) { root = b; have = true; }      // root exactly at the upper end
             else if (fa == 0.0 && k == 0) { root = a; have = true; }                     // root exactly at the lower end
             if (have) {
@@ -231,10 +244,13 @@ PA_HD void p4pf_charpoly(const double (&a)[50], double (&p)[11])
 
 // Action-matrix rows 5..9 (a[50], row-major 5x10) -> accepted roots, ascending zd.
 // Returns the count (0..6), or -1 when an eigenvector component is not finite.
+// STOP != 0 ends after a stage (1: characteristic polynomial, 2: root isolation); profiling only.
+template <int STOP = 0>
 PA_HD int p4pf_roots_sextic(const double (&a)[50], const p4pf_problem &pb, p4pf_root roots[10])
 {
     double p[11];
     p4pf_charpoly(a, p);
+    if (STOP == 1) { roots[0].f = p[2] + p[5] + p[10]; roots[0].zb = p[3]; roots[0].zc = p[4]; roots[0].zd = p[6] + p[7] + p[8] + p[9]; return 1; }
     // remove L^2 and ee(L) = |d|^2 L^2 - 2 a.d L + |a|^2
     const double ax = pb.m2D[0], ay = pb.m2D[1], dx = pb.m2D[6], dy = pb.m2D[7];
     const double e0 = ax * ax + ay * ay, e1 = -2.0 * (ax * dx + ay * dy), e2 = dx * dx + dy * dy;
@@ -272,8 +288,8 @@ PA_HD int p4pf_roots_sextic(const double (&a)[50], const p4pf_problem &pb, p4pf_
     // |L| <= 1 from q, |L| > 1 from the reversed polynomial (mu = 1/L in (-1, 1))
     double lam[12];
     double r1[6], r2[6];
-    const int n1 = poly_roots<6>::find(q, -1.0, 1.0, r1);
-    const int n2 = poly_roots<6>::find(qr, -1.0, 1.0, r2);
+    const int n1 = poly_roots<6>::find(q, -1.0, 1.0, r1, P4PF_REFINE_TOL_TOP);
+    const int n2 = poly_roots<6>::find(qr, -1.0, 1.0, r2, P4PF_REFINE_TOL_TOP);
     int nl = 0;
 #pragma unroll
     for (int i = 0; i < 6; ++i) if (i < n1) { lam[nl < 12 ? nl : 0] = r1[i]; ++nl; }
@@ -281,6 +297,7 @@ PA_HD int p4pf_roots_sextic(const double (&a)[50], const p4pf_problem &pb, p4pf_
     for (int i = 0; i < 6; ++i)
         if (i < n2 && fabs(r2[i]) < 1.0 && r2[i] != 0.0) { lam[nl < 12 ? nl : 0] = 1.0 / r2[i]; ++nl; }
     if (nl > 10) nl = 10;
+    if (STOP == 2) { roots[0].f = lam[0] + lam[1] + lam[2] + lam[3] + lam[4] + lam[5]; roots[0].zb = nl; roots[0].zc = 0; roots[0].zd = 0; return 1; }
     // derivative of the characteristic polynomial for the Newton polish
     double dp[10];
 #pragma unroll
@@ -290,18 +307,24 @@ PA_HD int p4pf_roots_sextic(const double (&a)[50], const p4pf_problem &pb, p4pf_
     for (int t = 0; t < nl; ++t) {
         double L = lam[t];
         double S[5][5], y[4];
-        for (int it = 0; it < 4; ++it) {
+        // Newton on det P(L).  The eigenvector of the last evaluation is kept once the step is
+        // below 1e-13 relative (its error is of the order of that step); a step above 5 % means
+        // the start was not in the basin of a root of det P and L is left where it is.
+        bool resolve = true;
+        for (int it = 0; it < 5; ++it) {
             p4pf_build_system(a, L, S);
             const double f = -p4pf_solve_system(S, y);      // = charpoly(L)
             const double df = poly_eval<9>(dp, L);
-            const double Ln = L - f / df;
-            if (!(Ln == Ln) || fabs(Ln - L) > 0.05 * fmax(1.0, fabs(L))) break;
-            const bool conv = fabs(Ln - L) <= 1e-15 * fmax(1.0, fabs(L));
-            L = Ln;
-            if (conv) break;
+            const double d = f / df;
+            const double scale = fmax(1.0, fabs(L));
+            if (!(d == d) || fabs(d) > 0.05 * scale) { resolve = false; break; }
+            L -= d;
+            if (fabs(d) <= 1e-13 * scale) { resolve = false; break; }
         }
-        p4pf_build_system(a, L, S);
-        p4pf_solve_system(S, y);
+        if (resolve) {
+            p4pf_build_system(a, L, S);
+            p4pf_solve_system(S, y);
+        }
         const double zc = y[0], zb = y[1], w = y[2];
         if (!(zc == zc) || !(zb == zb) || !(w == w)) nan = true;
         if (w > 0.00001) {

@@ -1,0 +1,92 @@
+// Stage timing of the P4Pf finish kernel on random minimal problems:
+//   stage 1 characteristic polynomial, 2 + deflation and real-root isolation,
+//   3 + Newton polish and eigenvector (complete eigen step), 4 + pose recovery (complete kernel body).
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <random>
+#include <vector>
+#include "../pose_estimation_amd/csrc/kernels.h"
+using namespace pose_amd;
+#define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
+
+template <int STAGE>
+__global__ void k_stage(uint32_t count, const double *__restrict__ m2d_in, const double *__restrict__ M3D_in,
+                        const double *__restrict__ Arows, const int *__restrict__ status, double *__restrict__ out)
+{
+    const size_t h = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (h >= count) return;
+    if (status[h] != 0) { out[h] = 0; return; }
+    double m2d[8], M3D[12];
+    for (int i = 0; i < 8; ++i) m2d[i] = m2d_in[8 * h + i];
+    for (int i = 0; i < 12; ++i) M3D[i] = M3D_in[12 * h + i];
+    p4pf_problem pb;
+    p4pf_normalise(m2d, M3D, pb);
+    double a[50];
+    for (int i = 0; i < 50; ++i) a[i] = Arows[h * 50 + i];
+    p4pf_root roots[10];
+    double acc = 0;
+    if (STAGE <= 2) {
+        const int n = p4pf_roots_sextic<STAGE>(a, pb, roots);
+        acc = n + roots[0].f + roots[0].zb + roots[0].zc + roots[0].zd;
+    } else {
+        const int n = p4pf_roots_sextic<0>(a, pb, roots);
+        acc = n;
+        for (int s = 0; s < n; ++s) {
+            if (STAGE == 3) acc += roots[s].f + roots[s].zd;
+            else { double f, R[9], t[3]; p4pf_pose_from_root(pb, roots[s], f, R, t); acc += f + R[0] + R[4] + R[8] + t[0] + t[1] + t[2]; }
+        }
+    }
+    out[h] = acc;
+}
+
+template <int STAGE>
+float run(uint32_t n, const double *m, const double *M, const double *A, const int *st, double *out)
+{
+    hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    k_stage<STAGE><<<(n + 63) / 64, 64>>>(n, m, M, A, st, out);
+    CHECK(hipDeviceSynchronize());
+    CHECK(hipEventRecord(e0));
+    k_stage<STAGE><<<(n + 63) / 64, 64>>>(n, m, M, A, st, out);
+    CHECK(hipEventRecord(e1));
+    CHECK(hipDeviceSynchronize());
+    float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+    return ms;
+}
+
+int main(int argc, char **argv)
+{
+    const uint32_t n = argc > 1 ? (uint32_t)atoi(argv[1]) : 524288;
+    std::mt19937_64 rng(7);
+    std::uniform_real_distribution<double> U(-1, 1);
+    std::vector<double> m((size_t)n * 8), M((size_t)n * 12);
+    for (uint32_t i = 0; i < n; ++i) {
+        const double f = 1300 + 700 * U(rng);
+        for (int k = 0; k < 4; ++k) {
+            const double X = U(rng) * 30, Y = U(rng) * 30, Z = 105 + 95 * U(rng);
+            m[8 * i + 2 * k] = (float)(f * X / Z + 0.3 * U(rng)); m[8 * i + 2 * k + 1] = (float)(f * Y / Z + 0.3 * U(rng));
+            M[12 * i + 3 * k] = (float)(X + 3); M[12 * i + 3 * k + 1] = (float)(Y - 2); M[12 * i + 3 * k + 2] = (float)(Z + 1);
+        }
+        if (i % 3) { const int k = (int)(rng() % 4); m[8 * i + 2 * k] = (float)(800 * U(rng)); m[8 * i + 2 * k + 1] = (float)(600 * U(rng)); }   // contaminated samples
+    }
+    double *dm, *dM, *dA, *dout; int *dst;
+    CHECK(hipMalloc(&dm, m.size() * 8)); CHECK(hipMalloc(&dM, M.size() * 8)); CHECK(hipMalloc(&dA, (size_t)n * 400));
+    CHECK(hipMalloc(&dout, (size_t)n * 8)); CHECK(hipMalloc(&dst, (size_t)n * 4));
+    CHECK(hipMemcpy(dm, m.data(), m.size() * 8, hipMemcpyHostToDevice)); CHECK(hipMemcpy(dM, M.data(), M.size() * 8, hipMemcpyHostToDevice));
+    query_dev q{};
+    hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    const int nbatch = (n + ELIM_BATCH - 1) / ELIM_BATCH;
+    for (int rep = 0; rep < 2; ++rep) {
+        CHECK(hipEventRecord(e0));
+        k_p4pf_elim<<<nbatch < 2048 ? nbatch : 2048, 64>>>(q, n, nullptr, dm, dM, dA, dst);
+        CHECK(hipEventRecord(e1));
+        CHECK(hipDeviceSynchronize());
+    }
+    float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+    printf("n = %u\nelimination            %.3f ms\n", n, ms);
+    printf("stage 1 charpoly       %.3f ms\n", run<1>(n, dm, dM, dA, dst, dout));
+    printf("stage 2 + isolation    %.3f ms\n", run<2>(n, dm, dM, dA, dst, dout));
+    printf("stage 3 + polish       %.3f ms\n", run<3>(n, dm, dM, dA, dst, dout));
+    printf("stage 4 + pose         %.3f ms\n", run<4>(n, dm, dM, dA, dst, dout));
+    return 0;
+}
