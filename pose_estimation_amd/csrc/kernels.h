@@ -192,11 +192,13 @@ __device__ __forceinline__ void gather_p4pf(const query_dev &q, const uint4 s, d
 // P4Pf, stage A+B: template coefficients and the cooperative elimination.
 // One wave per block.  Phase A: lanes 0..31 each prepare one hypothesis (gather the four
 // correspondences, normalise, 42 coefficients -> LDS).  Phase B: the whole wave eliminates
-// the 32 systems one after the other (p4pf_elim_wave) and writes rows 5..9 of each action
-// matrix (50 doubles) plus a status word.  Inputs come either from the resident query +
+// the 32 systems two at a time (p4pf_elim_wave) and writes the reduced 5 x 15 tail system of
+// each (75 doubles, stored [75][hyp_count] so that the consumer reads it coalesced) plus a
+// status word.  Inputs come either from the resident query +
 // sample tuples or, for the batch entry point, from explicit m2d / M3D arrays.
 // ------------------------------------------------------------------------------------------
 constexpr int ELIM_BATCH = 32;
+constexpr int P4PF_TAIL = 75;      // doubles per hypothesis between the elimination and the finish kernel, stored [75][count]
 
 __device__ __forceinline__ void p4pf_fetch(const query_dev &q, const uint32_t *__restrict__ samples, const double *__restrict__ m2d_in,
                                            const double *__restrict__ M3D_in, size_t h, double m2d[8], double M3D[12])
@@ -248,7 +250,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             if ((size_t)b * ELIM_BATCH + 2 * i >= hyp_count) break;
             const int st = st_s[sys];
             const bool live = h < hyp_count;
-            const int rc = p4pf_elim_wave(&cf[sys][0], Arows + (live ? h : 0) * 50, live && st == 0);
+            const int rc = p4pf_elim_wave(&cf[sys][0], Arows + (live ? h : 0), (size_t)hyp_count, live && st == 0);
             if ((lane & 31) == 0 && live) status[h] = st != 0 ? -1 : rc;
         }
         __syncthreads();
@@ -272,10 +274,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         double m2d[8], M3D[12];
         p4pf_fetch(q, samples, m2d_in, M3D_in, h, m2d, M3D);
         p4pf_normalise(m2d, M3D, pb);
-        double a[50];
+        double tl[5][15], a[50];
 #pragma unroll
-        for (int i = 0; i < 50; ++i) a[i] = Arows[h * 50 + i];
-        n = p4pf_roots_sextic(a, pb, roots);
+        for (int i = 0; i < P4PF_TAIL; ++i) tl[i / 15][i % 15] = Arows[(size_t)i * hyp_count + h];
+        n = p4pf_reduce_tail(tl, a);
+        if (n == 0) n = p4pf_roots_sextic(a, pb, roots);
     }
     nsol[h] = n;
     for (int s = 0; s < n; ++s) {

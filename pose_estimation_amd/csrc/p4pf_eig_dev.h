@@ -242,6 +242,44 @@ PA_HD void p4pf_charpoly(const double (&a)[50], double (&p)[11])
         }
 }
 
+// Tail of the template elimination: the reduced 5 x 15 system [K | B] (columns 70..74 | 78..87 of
+// the template, P4pf.cpp:1084) -> rows 5..9 of the action matrix, A(i, j) = -Mr(79 - i, 9 - j)
+// (P4pf.cpp:1098-1109), by Gauss-Jordan with partial pivoting.  Returns -1 on a zero pivot.
+PA_HD int p4pf_reduce_tail(double (&t)[5][15], double (&a)[50])
+{
+    bool bad = false;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+#pragma unroll
+        for (int p = k + 1; p < 5; ++p) {
+            if (fabs(t[p][k]) > fabs(t[k][k])) {
+#pragma unroll
+                for (int j = k; j < 15; ++j) { const double x = t[k][j]; t[k][j] = t[p][j]; t[p][j] = x; }
+            }
+        }
+        const double pv = t[k][k];
+        bad = bad || pv == 0.0;
+        const double ip = 1.0 / pv;
+#pragma unroll
+        for (int j = k + 1; j < 15; ++j) t[k][j] *= ip;
+#pragma unroll
+        for (int p = 0; p < 5; ++p) {
+            if (p == k) continue;
+            const double m = t[p][k];
+#pragma unroll
+            for (int j = k + 1; j < 15; ++j) t[p][j] = fma(-m, t[k][j], t[p][j]);
+        }
+    }
+    // row k now reads  x_(70+k) + sum_j t[k][5+j] x_(78+j) = 0
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        const int i = 9 - k;                     // action-matrix row of template column 70 + k
+#pragma unroll
+        for (int j = 0; j < 10; ++j) a[(i - 5) * 10 + j] = -t[k][5 + 9 - j];
+    }
+    return bad ? -1 : 0;
+}
+
 // Action-matrix rows 5..9 (a[50], row-major 5x10) -> accepted roots, ascending zd.
 // Returns the count (0..6), or -1 when an eigenvector component is not finite.
 // STOP != 0 ends after a stage (1: characteristic polynomial, 2: root isolation); profiling only.

@@ -105,7 +105,7 @@ static int launch_p4pf(pose_amd_ctx *ctx, uint32_t count, const uint32_t *sample
                        double *proj, double *pose, int *nsol, double *fo, double *Ro, double *to)
 {
     int rc;
-    if ((rc = ensure(ctx, ctx->arows, (size_t)count * 400)) || (rc = ensure(ctx, ctx->pstatus, (size_t)count * 4))) return rc;
+    if ((rc = ensure(ctx, ctx->arows, (size_t)count * P4PF_TAIL * 8)) || (rc = ensure(ctx, ctx->pstatus, (size_t)count * 4))) return rc;
     const query_dev q = make_query(ctx);
     const int nbatch = cdiv(count, ELIM_BATCH);
     const int max_blocks = (ctx->cus ? ctx->cus : 256) * 8;

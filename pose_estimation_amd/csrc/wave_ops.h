@@ -42,6 +42,18 @@ __device__ __forceinline__ int wave_argmax_abs(double x, bool cand)
     return (int)__builtin_ctzll(who | (1ull << 63));
 }
 
+// -1/x to about one ulp: hardware reciprocal seed plus two Newton steps (cheaper than the
+// IEEE division sequence; used for elimination multipliers).
+__device__ __forceinline__ double neg_rcp(double x)
+{
+    double y = __builtin_amdgcn_rcp(x);
+    double e = fma(-x, y, 1.0);
+    y = fma(y, e, y);
+    e = fma(-x, y, 1.0);
+    y = fma(y, e, y);
+    return -y;
+}
+
 // ---- the same for two independent 32-lane halves of a wave --------------------------------
 
 // Value of `v` in lane `src` (an absolute lane number; every lane of a half passes the same

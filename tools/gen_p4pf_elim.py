@@ -14,7 +14,9 @@ registers):
            Only the 29 rows that survive stage 1 are materialised (lanes 0..28 of each half).
   stage 2  the remaining 24 columns, dynamic partial pivoting over the 29 surviving rows
            (arg-max inside each half, pivot row broadcast with ds_bpermute).
-  stage 3  Gauss-Jordan on the 5 needed columns (70..74) of the last 5 rows.
+  tail     the 5 rows left over hold a 5 x 15 system in columns 70..74 | 78..87; it is written
+           out and solved per lane by the consumer (p4pf_reduce_tail), where it costs no
+           cross-lane traffic.
 
 The script also contains a NumPy interpreter of the same schedule (used by
 tests/test_p4pf_elim_schedule.py) so that the schedule is validated without a GPU.
@@ -235,8 +237,9 @@ def emit(sched):
     w("// cf: LDS array of 43 doubles holding the 42 template coefficients of this lane's system and")
     w("// 0.0 at index 42 (the pointer differs between the two halves of the wave).")
     w("// Returns 0, or -1 when a pivot is exactly zero (same value in all lanes of a half).")
-    w("// out5x10[(i-5)*10 + j] = A(i, j), i = 5..9, written by single lanes of each half when wr is set.")
-    w("__device__ __forceinline__ int p4pf_elim_wave(const double *cf, double *out5x10, bool wr)")
+    w("// tail5x15: the 5 rows that survive stage 2, columns 70..74 | 78..87; entry (r, j) goes to")
+    w("// tail5x15[(r * 15 + j) * stride], written by single lanes of each half when wr is set.")
+    w("__device__ __forceinline__ int p4pf_elim_wave(const double *cf, double *tail5x15, size_t stride, bool wr)")
     w("{")
     w("    const int lane = (int)(threadIdx.x & 63);")
     w("    const int row = lane & 31;")
@@ -309,37 +312,25 @@ def emit(sched):
         w("        const int L0 = __builtin_amdgcn_readfirstlane(L), L1 = __builtin_amdgcn_readlane(L, 32);")
         w(f"        const double pv = half_bcast(r{c}, L);")
         w("        bad |= pv == 0.0;")
-        w(f"        const double m = (active && lane != L) ? -r{c} / pv : 0.0;")
+        w(f"        const double m = (active && lane != L) ? r{c} * neg_rcp(pv) : 0.0;")
         bcast_fma(st["pattern"], 8)
         w("        active = active && lane != L;")
         w("    }")
-    # ---- stage 3
+    # ---- tail: the five rows still active hold the reduced 5 x 15 system (columns KEEP | RHS);
+    # its Gauss-Jordan solve needs no cross-lane traffic when done per lane by the consumer.
     for c in KEEP + RHS:
         need(c)
-    w("    bool pool = active;")
-    w("    int lane_of_col[5];")
-    for c in KEEP:
-        others = [c2 for c2 in KEEP + RHS if c2 != c]
-        w(f"    {{ // stage 3: column {c}")
-        w(f"        const int L = half_argmax_abs(r{c}, pool);")
-        w("        const int L0 = __builtin_amdgcn_readfirstlane(L), L1 = __builtin_amdgcn_readlane(L, 32);")
-        w(f"        const double pv = half_bcast(r{c}, L);")
-        w("        bad |= pv == 0.0;")
-        w(f"        const double m = (active && lane != L) ? -r{c} / pv : 0.0;")
-        bcast_fma(others, 7)
-        w(f"        r{c} = lane == L ? r{c} : 0.0;   // the column is now eliminated from every other row")
-        w("        pool = pool && lane != L;")
-        w(f"        lane_of_col[{c - 70}] = L;")
-        w("    }")
-    w("    // every pivot row is now reduced: row i of the action matrix is A(i, j) = -Mr(79 - i, 9 - j)")
-    for c in KEEP:
-        i = 79 - c
-        w(f"    if (wr && lane == lane_of_col[{c - 70}]) {{")
-        w(f"        const double s = -1.0 / r{c};")
-        w(f"        double *o = out5x10 + {(i - 5) * 10};")
-        for j in range(10):
-            w(f"        o[{j}] = s * r{78 + 9 - j};")
-        w("    }")
+    w("    {")
+    w("        const unsigned long long act = __ballot(active);")
+    w("        const unsigned mine = upper ? (unsigned)(act >> 32) : (unsigned)act;")
+    w("        bad |= __popc(mine) != 5;")
+    w("        const int rank = __popc(mine & ((1u << row) - 1u));")
+    w("        if (wr && active && rank < 5) {")
+    w("            double *o = tail5x15 + (size_t)(rank * 15) * stride;")
+    for j, c in enumerate(KEEP + RHS):
+        w(f"            o[{j} * stride] = r{c};")
+    w("        }")
+    w("    }")
     w("    return bad ? -1 : 0;")
     w("}")
     w("} // namespace pose_amd")

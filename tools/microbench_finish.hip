@@ -22,8 +22,9 @@ __global__ void k_stage(uint32_t count, const double *__restrict__ m2d_in, const
     for (int i = 0; i < 12; ++i) M3D[i] = M3D_in[12 * h + i];
     p4pf_problem pb;
     p4pf_normalise(m2d, M3D, pb);
-    double a[50];
-    for (int i = 0; i < 50; ++i) a[i] = Arows[h * 50 + i];
+    double tl[5][15], a[50];
+    for (int i = 0; i < P4PF_TAIL; ++i) tl[i / 15][i % 15] = Arows[(size_t)i * count + h];
+    if (p4pf_reduce_tail(tl, a) != 0) { out[h] = -1; return; }
     p4pf_root roots[10];
     double acc = 0;
     if (STAGE <= 2) {
@@ -70,7 +71,7 @@ int main(int argc, char **argv)
         if (i % 3) { const int k = (int)(rng() % 4); m[8 * i + 2 * k] = (float)(800 * U(rng)); m[8 * i + 2 * k + 1] = (float)(600 * U(rng)); }   // contaminated samples
     }
     double *dm, *dM, *dA, *dout; int *dst;
-    CHECK(hipMalloc(&dm, m.size() * 8)); CHECK(hipMalloc(&dM, M.size() * 8)); CHECK(hipMalloc(&dA, (size_t)n * 400));
+    CHECK(hipMalloc(&dm, m.size() * 8)); CHECK(hipMalloc(&dM, M.size() * 8)); CHECK(hipMalloc(&dA, (size_t)n * P4PF_TAIL * 8));
     CHECK(hipMalloc(&dout, (size_t)n * 8)); CHECK(hipMalloc(&dst, (size_t)n * 4));
     CHECK(hipMemcpy(dm, m.data(), m.size() * 8, hipMemcpyHostToDevice)); CHECK(hipMemcpy(dM, M.data(), M.size() * 8, hipMemcpyHostToDevice));
     query_dev q{};
