@@ -276,13 +276,16 @@ def emit(sched):
             for c2 in via_lds:
                 w(f"        r{c2} = fma(m, e{c2}, r{c2});")
             if via_alu:
-                w("        if (upper) {")
-                for c2 in via_alu:
-                    w(f"            r{c2} = fma(m, b{c2}, r{c2});")
-                w("        } else {")
-                for c2 in via_alu:
-                    w(f"            r{c2} = fma(m, a{c2}, r{c2});")
-                w("        }")
+                # two half-masked FMAs per column with the scalar operand read directly (the
+                # compiler would select between the halves with moves + v_cndmask instead)
+                lines = ['"s_mov_b32 exec_hi, 0\\n\\t"']
+                lines += [f'"v_fmac_f64 %[r{c2}], %[a{c2}], %[m]\\n\\t"' for c2 in via_alu]
+                lines += ['"s_mov_b32 exec_lo, 0\\n\\t"', '"s_mov_b32 exec_hi, -1\\n\\t"']
+                lines += [f'"v_fmac_f64 %[r{c2}], %[b{c2}], %[m]\\n\\t"' for c2 in via_alu]
+                lines += ['"s_mov_b32 exec_lo, -1"']
+                w("        asm volatile(" + "\n                     ".join(lines))
+                w("                     : " + ", ".join(f'[r{c2}] "+v"(r{c2})' for c2 in via_alu))
+                w("                     : [m] \"v\"(m), " + ", ".join(f'[a{c2}] "s"(a{c2}), [b{c2}] "s"(b{c2})' for c2 in via_alu) + ");")
 
     # ---- stage 1
     for si, st in enumerate(sched["steps"]):
