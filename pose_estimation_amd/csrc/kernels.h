@@ -20,6 +20,8 @@ struct query_dev {
     const float *kx, *ky, *X, *Y, *Z;
     const uint32_t *lindex;            // may be null (identity)
     const uint32_t *cam_off, *cam_ids; // may be null
+    float xmax;                        // max over the query of |X|, |Y|, |Z|
+    float umax;                        // max over the query of |kx - w/2|, |ky - h/2|
 };
 
 __device__ __forceinline__ uint32_t lindex_of(const query_dev &q, uint32_t i) { return q.lindex ? q.lindex[i] : i; }
@@ -429,6 +431,181 @@ __global__ __launch_bounds__(SCORE_THREADS) void k_score(query_dev q, int nslots
                     if (MASK) {
                         const int word = (base + k * SCORE_THREADS + wave * 64) >> 6;
                         if (lane == 0 && word < words_per_pose) mask[(size_t)slot * words_per_pose + word] = b;
+                    }
+                }
+                if (lane == 0 && cnt) atomicAdd(&s_cnt[slot - slot0], cnt);
+            }
+        }
+    }
+    __syncthreads();
+    if (slot0 + tid < nslots) counts[slot0 + tid] = s_cnt[tid];
+}
+
+// ------------------------------------------------------------------------------------------
+// Scoring with a float32 screen.
+//
+// Nearly every (pose, correspondence) pair is far outside the threshold.  The screen evaluates
+// the same residual in packed float32 (two correspondences per instruction) and certifies
+// "outside" only when the float32 value exceeds the threshold by more than a rigorous bound of
+// its own rounding error; every correspondence group in which some lane is not certified is
+// re-evaluated with the float64 test above, whose result alone decides.  Counts and masks are
+// therefore identical to k_score's.
+//
+// Bound.  eps32 = 2^-24.  With Sz >= sum_j |P2j||X~j| and Sxy likewise for rows 0 and 1 (from
+// the pose's row sums, the query's largest coordinate and its largest |u|, |v|):
+//   |pz32 - pz| <= 4.01 eps32 Sz,  |rx32 - rx| <= E + 2 eps32 |rx|,
+//   E = 1.01 eps32 (5.02 umax Sz + 4.01 Sxy).
+// D > |te| is implied by D32 > k1 T + c with T = eps |pz32|, k1 = 1 + 2 eps32,
+// c = 1.0001 eps 4.01 eps32 Sz + 1.4143 E, and (k1 T + c)^2 <= T^2 (k1^2 + kappa) +
+// c^2 (1 + k1^2 / kappa), kappa = 2^-6.  The factors (1 + 2^-20) below absorb the roundings of
+// the float32 evaluation of both sides.  (Certifying "inside" the same way was tried: the two
+// extra packed operations per pair cost more than the float64 re-evaluations they save.)
+// ------------------------------------------------------------------------------------------
+typedef float v2f __attribute__((ext_vector_type(2)));
+constexpr int SCREEN_KC = 8;         // correspondences per lane and tile (four packed pairs)
+
+// proj (12 doubles) -> 32 floats: every entry twice (operand pairs of the packed
+// instructions), then the additive constant B of the screen twice.
+__global__ void k_make_projf(query_dev q, int nslots, const double *__restrict__ proj, const int *__restrict__ nsol, int maxsol,
+                             double eps, float *__restrict__ projf)
+{
+    const int slot = blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot >= nslots) return;
+    if (nsol && (slot % maxsol) >= nsol[slot / maxsol]) return;
+    double P[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) P[i] = proj[(size_t)slot * 12 + i];
+    const double e32 = 5.9604644775390625e-08, xm = (double)q.xmax, um = (double)q.umax;
+    double S[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) S[r] = (fabs(P[4 * r]) + fabs(P[4 * r + 1]) + fabs(P[4 * r + 2])) * xm + fabs(P[4 * r + 3]);
+    const double E = 1.01 * e32 * (5.02 * um * S[2] + 4.01 * fmax(S[0], S[1]));
+    const double c = 1.0001 * eps * 4.01 * e32 * S[2] + 1.4143 * E;
+    const double k1 = 1.0 + 2.0 * e32, kappa = 0.015625;
+    double B = c * c * (1.0 + k1 * k1 / kappa) * (1.0 + 9.5367431640625e-07);
+    float Bf = (float)B;
+    if ((double)Bf < B) Bf = __uint_as_float(__float_as_uint(Bf) + 1u);     // round up (B >= 0)
+    if (!(B == B) || !(B < 3.0e38)) Bf = __uint_as_float(0x7f800000u);      // never certifies
+    float4 *o = reinterpret_cast<float4 *>(projf + (size_t)slot * 32);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) o[i] = make_float4((float)P[2 * i], (float)P[2 * i], (float)P[2 * i + 1], (float)P[2 * i + 1]);
+    o[6] = make_float4(Bf, Bf, 0.f, 0.f);
+    o[7] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+__device__ __forceinline__ v2f pk_fma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+
+struct posef { v2f p[12]; v2f B; };
+__device__ __forceinline__ void load_posef_uniform(const float *__restrict__ projf, int slot, posef &o)
+{
+    const v2f *__restrict__ p = reinterpret_cast<const v2f *>(projf + (size_t)slot * 32);
+#pragma unroll
+    for (int i = 0; i < 12; ++i) o.p[i] = p[i];
+    o.B = p[12];
+}
+
+template <bool MASK>
+__global__ __launch_bounds__(SCORE_THREADS) void k_score_screen(query_dev q, int nslots, const double *__restrict__ proj,
+                                                                const float *__restrict__ projf, const int *__restrict__ nsol,
+                                                                int maxsol, double eps, int *__restrict__ counts,
+                                                                unsigned long long *__restrict__ mask, int words_per_pose)
+{
+    constexpr int KC = SCREEN_KC;
+    __shared__ int s_cnt[SCORE_SPB];
+    __shared__ int s_list[SCORE_SPB];
+    __shared__ int s_wave_n[SCORE_THREADS / 64];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int slot0 = blockIdx.x * SCORE_SPB;
+    {
+        const int slot = slot0 + tid;
+        bool valid = slot < nslots;
+        if (valid && nsol) valid = (slot % maxsol) < nsol[slot / maxsol];
+        s_cnt[tid] = 0;
+        const unsigned long long b = __ballot(valid);
+        if (lane == 0) s_wave_n[wave] = __popcll(b);
+        __syncthreads();
+        int base = 0;
+#pragma unroll
+        for (int w = 0; w < SCORE_THREADS / 64; ++w) if (w < wave) base += s_wave_n[w];
+        if (valid) s_list[base + __popcll(b & ((1ull << lane) - 1ull))] = slot;
+        __syncthreads();
+    }
+    int nvalid = 0;
+#pragma unroll
+    for (int w = 0; w < SCORE_THREADS / 64; ++w) nvalid += s_wave_n[w];
+    nvalid = __builtin_amdgcn_readfirstlane(nvalid);
+    if (nvalid > 0) {
+        const double hw = (double)q.width / 2.0, hh = (double)q.height / 2.0;
+        // KA >= eps^2 (k1^2 + kappa), rounded up
+        const double KAd = eps * eps * ((1.0 + 1.1920928955078125e-07) * (1.0 + 1.1920928955078125e-07) + 0.015625) * (1.0 + 9.5367431640625e-07);
+        float KAf = (float)KAd;
+        if ((double)KAf < KAd) KAf = __uint_as_float(__float_as_uint(KAf) + 1u);
+        const v2f KA = {KAf, KAf};
+        const int tile_sz = SCORE_THREADS * KC;
+        for (int base = 0; base < q.n; base += tile_sz) {
+            float kx[KC], ky[KC];
+            v2f u[KC / 2], v[KC / 2], X[KC / 2], Y[KC / 2], Z[KC / 2];
+#pragma unroll
+            for (int k = 0; k < KC; ++k) {
+                const int idx = base + k * SCORE_THREADS + tid;
+                const bool ok = idx < q.n;
+                kx[k] = ok ? q.kx[idx] : 0.f; ky[k] = ok ? q.ky[idx] : 0.f;
+                const float x = ok ? q.X[idx] : 0.f, y = ok ? q.Y[idx] : 0.f, z = ok ? q.Z[idx] : 0.f;
+                // lanes past the end get an observation so far away that the screen certifies them
+                // outside (should it not, the float64 test below rejects them by index)
+                const float uf = ok ? (float)(-((double)kx[k] - hw)) : 1e18f, vf = ok ? (float)(-((double)ky[k] - hh)) : 1e18f;
+                if (k & 1) { u[k / 2].y = uf; v[k / 2].y = vf; X[k / 2].y = x; Y[k / 2].y = y; Z[k / 2].y = z; }
+                else { u[k / 2].x = uf; v[k / 2].x = vf; X[k / 2].x = x; Y[k / 2].x = y; Z[k / 2].x = z; }
+            }
+            int slot_n = __builtin_amdgcn_readfirstlane(s_list[0]);
+            posef Pn;
+            load_posef_uniform(projf, slot_n, Pn);
+            for (int i = 0; i < nvalid; ++i) {
+                const int slot = slot_n;
+                const posef P = Pn;
+                if (i + 1 < nvalid) {
+                    slot_n = __builtin_amdgcn_readfirstlane(s_list[i + 1]);
+                    load_posef_uniform(projf, slot_n, Pn);
+                }
+                int cnt = 0;
+                // the translation column once per pose in vector registers: a packed FMA reads at
+                // most one scalar operand
+                v2f tx = P.p[3], ty = P.p[7], tz = P.p[11];
+                asm volatile("" : "+v"(tx), "+v"(ty), "+v"(tz));
+#pragma unroll
+                for (int g = 0; g < KC / 2; ++g) {
+                    const v2f px = pk_fma(P.p[0], X[g], pk_fma(P.p[1], Y[g], pk_fma(P.p[2], Z[g], tx)));
+                    const v2f py = pk_fma(P.p[4], X[g], pk_fma(P.p[5], Y[g], pk_fma(P.p[6], Z[g], ty)));
+                    const v2f pz = pk_fma(P.p[8], X[g], pk_fma(P.p[9], Y[g], pk_fma(P.p[10], Z[g], tz)));
+                    const v2f rx = pk_fma(u[g], pz, -px), ry = pk_fma(v[g], pz, -py);
+                    const v2f d2 = pk_fma(ry, ry, rx * rx);
+                    const v2f hi2 = pk_fma(pz * pz, KA, P.B);
+                    // lanes not certified outside, per correspondence of the pair
+                    const unsigned long long n0 = ~__ballot(d2.x > hi2.x);
+                    const unsigned long long n1 = ~__ballot(d2.y > hi2.y);
+                    if (n0 | n1) {
+                        double Pd[12];
+                        load_pose_uniform(proj, slot, Pd);
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            const int k = 2 * g + h;
+                            if ((h ? n1 : n0) == 0) continue;
+                            const bool ok = base + k * SCORE_THREADS + tid < q.n;
+                            const double ud = -((double)kx[k] - hw), vd = -((double)ky[k] - hh);
+                            const double Xd = (double)(h ? X[g].y : X[g].x), Yd = (double)(h ? Y[g].y : Y[g].x), Zd = (double)(h ? Z[g].y : Z[g].x);
+                            const double qx = fma(Pd[0], Xd, fma(Pd[1], Yd, fma(Pd[2], Zd, Pd[3])));
+                            const double qy = fma(Pd[4], Xd, fma(Pd[5], Yd, fma(Pd[6], Zd, Pd[7])));
+                            const double qz = fma(Pd[8], Xd, fma(Pd[9], Yd, fma(Pd[10], Zd, Pd[11])));
+                            const double sx = fma(ud, qz, -qx), sy = fma(vd, qz, -qy);
+                            const double e2 = fma(sy, sy, sx * sx);
+                            const double te = eps * qz;
+                            const unsigned long long b = __ballot(ok && e2 < te * te);
+                            cnt += __popcll(b);
+                            if (MASK && b) {
+                                const int word = (base + k * SCORE_THREADS + wave * 64) >> 6;
+                                if (lane == 0 && word < words_per_pose) mask[(size_t)slot * words_per_pose + word] = b;
+                            }
+                        }
                     }
                 }
                 if (lane == 0 && cnt) atomicAdd(&s_cnt[slot - slot0], cnt);

@@ -33,6 +33,9 @@ struct pose_amd_ctx {
     double focal = 0;
     dev_buf kx, ky, X, Y, Z, lindex, cam_off, cam_ids, gain;
     bool has_lindex = false, has_cam = false;
+    float xmax = 0, umax = 0;      // largest |coordinate| and largest |centred keypoint coordinate| of the query
+    bool score_fp64_only = false;  // POSE_AMD_SCORE=fp64: skip the float32 screen (for A/B checks)
+    dev_buf projf;
     // hypotheses
     uint32_t hyp_count = 0;
     int solver = POSE_AMD_SOLVER_P4PF;
@@ -94,6 +97,7 @@ static query_dev make_query(const pose_amd_ctx *c)
     q.lindex = c->has_lindex ? (const uint32_t *)c->lindex.p : nullptr;
     q.cam_off = c->has_cam ? (const uint32_t *)c->cam_off.p : nullptr;
     q.cam_ids = c->has_cam ? (const uint32_t *)c->cam_ids.p : nullptr;
+    q.xmax = c->xmax; q.umax = c->umax;
     return q;
 }
 
@@ -145,6 +149,8 @@ int pose_amd_create(int device, pose_amd_ctx **out)
     snprintf(c->dev_name, sizeof c->dev_name, "%s (%s)", prop.name, prop.gcnArchName);
     c->cus = prop.multiProcessorCount;
     c->clock_khz = prop.clockRate;
+    const char *sm = getenv("POSE_AMD_SCORE");
+    c->score_fp64_only = sm && strcmp(sm, "fp64") == 0;
     if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
     for (int i = 0; i < 6; ++i)
         if ((e = hipEventCreate(&c->ev[i])) != hipSuccess) return bail("hipEventCreate", e);
@@ -165,7 +171,7 @@ void pose_amd_destroy(pose_amd_ctx *c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     dev_buf *bufs[] = {&c->kx, &c->ky, &c->X, &c->Y, &c->Z, &c->lindex, &c->cam_off, &c->cam_ids, &c->gain, &c->samples,
                        &c->sample_status, &c->proj, &c->pose, &c->nsol, &c->counts, &c->sel, &c->bitmaps, &c->areas,
-                       &c->maskw, &c->arows, &c->pstatus, &c->in0, &c->in1, &c->in2, &c->out0, &c->out1, &c->out2, &c->out3};
+                       &c->maskw, &c->arows, &c->pstatus, &c->projf, &c->in0, &c->in1, &c->in2, &c->out0, &c->out1, &c->out2, &c->out3};
     for (dev_buf *b : bufs) if (b->p) (void)hipFree(b->p);
     for (int i = 0; i < 6; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -266,6 +272,17 @@ int pose_amd_set_query(pose_amd_ctx *ctx, int n, const float *kx, const float *k
     ctx->has_lindex = lindex != nullptr;
     if (lindex && (rc = upload(ctx, ctx->lindex, lindex, b))) return rc;
     ctx->n = n; ctx->width = width; ctx->height = height; ctx->focal = focal;
+    // magnitudes for the error bound of the float32 screen; a NaN makes the bound NaN, which
+    // sends every pair to the float64 test
+    float xm = 0.f, um = 0.f;
+    bool finite = true;
+    for (int i = 0; i < n; ++i) {
+        const float a = std::fmax(std::fabs(X[i]), std::fmax(std::fabs(Y[i]), std::fabs(Z[i])));
+        const float u = (float)std::fmax(std::fabs((double)kx[i] - width / 2.0), std::fabs((double)ky[i] - height / 2.0));
+        finite = finite && a == a && u == u;
+        xm = std::fmax(xm, a); um = std::fmax(um, u);
+    }
+    ctx->xmax = finite ? xm : NAN; ctx->umax = finite ? um * 1.000001f : NAN;
     ctx->solver = focal == 0.0 ? POSE_AMD_SOLVER_P4PF : POSE_AMD_SOLVER_P3P;
     ctx->has_cam = false;
     ctx->hyp_count = 0;
@@ -319,6 +336,20 @@ static int launch_score(pose_amd_ctx *ctx, int nslots, const double *proj_dev, c
 {
     const query_dev q = make_query(ctx);
     const dim3 grid(cdiv(nslots, SCORE_SPB)), block(SCORE_THREADS);
+    if (!ctx->score_fp64_only) {
+        int rc;
+        if ((rc = ensure(ctx, ctx->projf, (size_t)nslots * 128))) return rc;
+        hipLaunchKernelGGL(k_make_projf, dim3(cdiv(nslots, 256)), dim3(256), 0, ctx->stream, q, nslots, proj_dev, nsol_dev, maxsol, eps,
+                           (float *)ctx->projf.p);
+        if (mask_dev)
+            hipLaunchKernelGGL((k_score_screen<true>), grid, block, 0, ctx->stream, q, nslots, proj_dev, (const float *)ctx->projf.p,
+                               nsol_dev, maxsol, eps, counts_dev, mask_dev, words_per_pose);
+        else
+            hipLaunchKernelGGL((k_score_screen<false>), grid, block, 0, ctx->stream, q, nslots, proj_dev, (const float *)ctx->projf.p,
+                               nsol_dev, maxsol, eps, counts_dev, (unsigned long long *)nullptr, 0);
+        HIPCHK(ctx, hipGetLastError());
+        return POSE_AMD_OK;
+    }
     if (mask_dev)
         hipLaunchKernelGGL((k_score<4, true>), grid, block, 0, ctx->stream, q, nslots, proj_dev, nsol_dev, maxsol, eps, counts_dev,
                            mask_dev, words_per_pose);

@@ -15,6 +15,14 @@ def random_rotation(rng):
     return q
 
 
+def small_rotation(rng, angle):
+    """Rotation by `angle` radians about a random axis (Rodrigues)."""
+    a = rng.normal(size=3)
+    a /= np.linalg.norm(a)
+    K = np.array([[0, -a[2], a[1]], [a[2], 0, -a[0]], [-a[1], a[0], 0]])
+    return np.eye(3) + np.sin(angle) * K + (1 - np.cos(angle)) * (K @ K)
+
+
 def make_query(n, inlier_frac, seed, width=1600, height=1200, focal=1200.0, noise_px=0.3, known_focal=False,
                depth=(10.0, 200.0)):
     """One synthetic query.  Returns a dict with kx, ky, X, Y, Z (float32), width, height,

@@ -407,3 +407,36 @@ def test_advanced_sampler_fixture(ctx):
     ctx.set_camsets(np.array(fx["cam_off"], np.uint32), np.array(fx["cam_ids"], np.uint32))
     got = ctx.sample(SAMPLE_ADVANCED, fx["seed"], fx["query_id"], 0, len(fx["tuples"]))
     assert got.tolist() == fx["tuples"]
+
+
+# ---- float32 screen of the scoring kernel ------------------------------------------------------
+@pytest.mark.gpu
+def test_score_screen_equals_float64_kernel(ctx):
+    """The screened kernel must return exactly what the float64-only kernel returns: poses at
+    all distances from the truth (so that residuals land on both sides of, and very near, the
+    threshold), world coordinates far from the origin (large cancellation), odd sizes."""
+    from pose_estimation_amd import Context
+    os.environ["POSE_AMD_SCORE"] = "fp64"
+    try:
+        ref_ctx = Context(0)
+    finally:
+        del os.environ["POSE_AMD_SCORE"]
+    rng = np.random.default_rng(12)
+    with ref_ctx:
+        for n, shift in ((4099, 0.0), (1000, 5000.0), (63, 0.0)):
+            q = synth.make_query(n, 0.6, 5 + n, noise_px=0.7)      # noise around the 0.5 px threshold
+            q["X"] = (q["X"] + np.float32(shift)).astype(np.float32)
+            Ctrue = q["C_true"] + np.array([shift, 0.0, 0.0])
+            poses = []
+            for i in range(600):
+                s = 10.0 ** rng.uniform(-9, 0)
+                poses.append(O.compute_matrices(q["f_true"] * (1 + s * rng.normal() * 1e-2), Ctrue + s * rng.normal(size=3),
+                                                q["Rc_true"] @ synth.small_rotation(rng, s * 1e-2)))
+            P = np.array(poses)
+            for c in (ctx, ref_ctx):
+                upload(c, q)
+            for eps in (0.5, 0.37):
+                c1, m1 = ctx.score_batch(P, eps, want_masks=True)
+                c0, m0 = ref_ctx.score_batch(P, eps, want_masks=True)
+                assert np.array_equal(c1, c0) and np.array_equal(m1, m0)
+                assert c0.max() > 0.1 * n and c0.min() < 0.05 * n
