@@ -42,7 +42,15 @@ def main():
     ap.add_argument("--inlier-frac", type=float, default=0.10)
     ap.add_argument("--cpu-hyps", type=int, default=0, help="CPU baseline sample size (0 = auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", choices=["single", "dubrovnik"], default="single",
+                    help="single: BASELINE configs[1] (default, the headline line); dubrovnik: configs[2], 800 queries sharded by query")
+    ap.add_argument("--queries", type=int, default=800)
+    ap.add_argument("--budget", type=int, default=10000, help="dubrovnik: hypotheses per query")
+    ap.add_argument("--early-exit", action="store_true", help="dubrovnik: the reference's loop (coverage quality, stop at 12 inliers)")
+    ap.add_argument("--host-threads", type=int, default=4, help="dubrovnik: contexts (streams) per GPU driven concurrently")
     args = ap.parse_args()
+    if args.workload == "dubrovnik":
+        return bench_dubrovnik(args)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -138,6 +146,104 @@ def main():
             out["cpu_baseline"] = cpu_baseline(ctx, q, args)
         print(json.dumps(out))
     ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+    return 0
+
+
+def bench_dubrovnik(args):
+    """BASELINE configs[2]: 800 Dubrovnik6K-shaped synthetic queries (image sizes and known /
+    unknown focal lengths of the real query list, 4 000-6 000 matches, 10-40 % inliers), basic
+    RANSAC per query, queries partitioned over the GPUs (no collective in the data path).
+    A step is one pass over all queries.  Each GPU is driven by a few host threads, one
+    context (HIP stream) each, so that the small per-query launches of different queries overlap."""
+    from concurrent.futures import ThreadPoolExecutor
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    from pose_estimation_amd import Context, shard, synth, SELECT_INLIERS, SELECT_COVERAGE, SAMPLE_BASIC
+    with open(os.path.join(ROOT, "tests", "golden", "dubrovnik_queries.json")) as f:
+        shapes = json.load(f)["queries"]
+    nq = args.queries
+    rng = np.random.default_rng(3)
+    sizes = rng.integers(4000, 6001, nq)
+    fracs = rng.uniform(0.10, 0.40, nq)
+    mine = shard.query_shard(sizes, rank, world)
+    queries = []
+    for qi in mine:
+        w, h, f = shapes[qi % len(shapes)]
+        q = synth.make_query(int(sizes[qi]), float(fracs[qi]), 3000 + qi, width=w, height=h, focal=f if f > 0 else 0.9 * max(w, h),
+                             known_focal=f > 0)
+        queries.append((qi, q))
+    T = max(1, args.host_threads)
+    ctxs = [Context(local_rank) for _ in range(T)]
+    select = SELECT_COVERAGE if args.early_exit else SELECT_INLIERS
+
+    def run_part(t):
+        ctx = ctxs[t]
+        out = []
+        for qi, q in queries[t::T]:
+            ctx.set_query(q["kx"], q["ky"], q["X"], q["Y"], q["Z"], q["width"], q["height"], q["focal"])
+            ctx.sample(SAMPLE_BASIC, 3000, qi, 0, args.budget, export=False)
+            r = ctx.ransac_run(select, 0.5, early_exit=args.early_exit)
+            out.append((qi, r["steps"], r["inliers"], float(np.linalg.norm(r["C"] - q["C_true"])) if r["found"] else float("inf")))
+        return out
+
+    def one_pass(pool):
+        res = []
+        for part in pool.map(run_part, range(T)):
+            res.extend(part)
+        return res
+
+    def sync():
+        for c in ctxs:
+            c.synchronize()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    with ThreadPoolExecutor(T) as pool:
+        for _ in range(args.warmup):
+            one_pass(pool)
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            res = one_pass(pool)
+        sync()
+        dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        stats = [None] * world
+        dist.all_gather_object(stats, res)
+        res = [x for part in stats for x in part]
+    if rank == 0:
+        steps_total = sum(r[1] for r in res)
+        located = sum(1 for r in res if r[3] < 2.0)
+        out = {"metric": "queries/sec (Dubrovnik-shaped batch, basic RANSAC)", "value": round(nq * args.steps / dt, 1), "unit": "queries/s",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+               "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+               "config": {"workload": "BASELINE configs[2]: %d Dubrovnik6K-shaped queries (real image sizes, %d known / %d unknown focal), "
+                                      "4000-6000 matches, 10-40%% inliers, %s"
+                                      % (nq, sum(1 for i in range(nq) if shapes[i % len(shapes)][2] > 0),
+                                         sum(1 for i in range(nq) if shapes[i % len(shapes)][2] == 0),
+                                         "reference loop: coverage quality, early exit, <= %d steps" % args.budget if args.early_exit
+                                         else "fixed budget of %d hypotheses per query, inlier-count selection" % args.budget),
+                          "parallelism": "queries partitioned over %d GPU(s), %d host threads (contexts) per GPU" % (world, T),
+                          "hypotheses_per_s": round(steps_total * args.steps / dt, 1),
+                          "mean_steps_per_query": round(steps_total / max(len(res), 1), 1),
+                          "queries_within_2_units_of_true_position": located}}
+        print(json.dumps(out))
+    for c in ctxs:
+        c.close()
     if world > 1:
         dist.destroy_process_group()
     return 0

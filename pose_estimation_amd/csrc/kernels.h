@@ -199,7 +199,8 @@ __device__ __forceinline__ void gather_p4pf(const query_dev &q, const uint4 s, d
 // status word.  Inputs come either from the resident query +
 // sample tuples or, for the batch entry point, from explicit m2d / M3D arrays.
 // ------------------------------------------------------------------------------------------
-constexpr int ELIM_BATCH = 32;
+constexpr int ELIM_BATCH = 32;     // systems per block and round at most; the launch passes an even `batch` <= this
+                                   // (small launches use small batches so that they still fill the chip)
 constexpr int P4PF_TAIL = 75;      // doubles per hypothesis between the elimination and the finish kernel, stored [75][count]
 
 __device__ __forceinline__ void p4pf_fetch(const query_dev &q, const uint32_t *__restrict__ samples, const double *__restrict__ m2d_in,
@@ -217,15 +218,15 @@ __device__ __forceinline__ void p4pf_fetch(const query_dev &q, const uint32_t *_
 
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_p4pf_elim(query_dev q, uint32_t hyp_count, const uint32_t *__restrict__ samples,
                                                   const double *__restrict__ m2d_in, const double *__restrict__ M3D_in,
-                                                  double *__restrict__ Arows, int *__restrict__ status)
+                                                  double *__restrict__ Arows, int *__restrict__ status, int batch)
 {
     __shared__ double cf[ELIM_BATCH][43];
     __shared__ int st_s[ELIM_BATCH];
     const int lane = threadIdx.x;
-    const uint32_t nbatch = (hyp_count + ELIM_BATCH - 1) / ELIM_BATCH;
+    const uint32_t nbatch = (hyp_count + batch - 1) / batch;
     for (uint32_t b = blockIdx.x; b < nbatch; b += gridDim.x) {
-        if (lane < ELIM_BATCH) {
-            const size_t h = (size_t)b * ELIM_BATCH + lane;
+        if (lane < batch) {
+            const size_t h = (size_t)b * batch + lane;
             int st = -1;
             double k[42];
 #pragma unroll
@@ -246,10 +247,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         }
         __syncthreads();
         // two systems per pass: lanes 0..31 eliminate system 2i, lanes 32..63 system 2i+1
-        for (int i = 0; i < ELIM_BATCH / 2; ++i) {
+        for (int i = 0; i < batch / 2; ++i) {
             const int sys = 2 * i + (lane >> 5);
-            const size_t h = (size_t)b * ELIM_BATCH + sys;
-            if ((size_t)b * ELIM_BATCH + 2 * i >= hyp_count) break;
+            const size_t h = (size_t)b * batch + sys;
+            if ((size_t)b * batch + 2 * i >= hyp_count) break;
             const int st = st_s[sys];
             const bool live = h < hyp_count;
             const int rc = p4pf_elim_wave(&cf[sys][0], Arows + (live ? h : 0), (size_t)hyp_count, live && st == 0);
@@ -349,7 +350,8 @@ __global__ void k_compute_matrices(int count, const double *__restrict__ focal, 
 // within rounding of the threshold.  Per-wave inlier counts come from ballot + popcount.
 // ------------------------------------------------------------------------------------------
 constexpr int SCORE_THREADS = 256;
-constexpr int SCORE_SPB = 256;       // pose slots per block
+constexpr int SCORE_SPB = 256;       // pose slots per block at most; the launch passes spb <= this (small launches use fewer
+                                     // slots per block so that they still fill the chip)
 
 __device__ __forceinline__ void load_pose_uniform(const double *__restrict__ proj, int slot, double (&P)[12])
 {
@@ -362,17 +364,17 @@ template <int KC, bool MASK>
 __global__ __launch_bounds__(SCORE_THREADS) void k_score(query_dev q, int nslots, const double *__restrict__ proj,
                                                          const int *__restrict__ nsol, int maxsol, double eps,
                                                          int *__restrict__ counts, unsigned long long *__restrict__ mask,
-                                                         int words_per_pose)
+                                                         int words_per_pose, int spb)
 {
     __shared__ int s_cnt[SCORE_SPB];
     __shared__ int s_list[SCORE_SPB];
     __shared__ int s_wave_n[SCORE_THREADS / 64];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int slot0 = blockIdx.x * SCORE_SPB;
+    const int slot0 = blockIdx.x * spb;
     // compact list of the block's valid slots (a hypothesis with nsol solutions owns slots 0..nsol-1)
     {
         const int slot = slot0 + tid;
-        bool valid = slot < nslots;
+        bool valid = tid < spb && slot < nslots;
         if (valid && nsol) valid = (slot % maxsol) < nsol[slot / maxsol];
         s_cnt[tid] = 0;
         const unsigned long long b = __ballot(valid);
@@ -438,7 +440,7 @@ __global__ __launch_bounds__(SCORE_THREADS) void k_score(query_dev q, int nslots
         }
     }
     __syncthreads();
-    if (slot0 + tid < nslots) counts[slot0 + tid] = s_cnt[tid];
+    if (tid < spb && slot0 + tid < nslots) counts[slot0 + tid] = s_cnt[tid];
 }
 
 // ------------------------------------------------------------------------------------------
@@ -508,17 +510,17 @@ template <bool MASK>
 __global__ __launch_bounds__(SCORE_THREADS) void k_score_screen(query_dev q, int nslots, const double *__restrict__ proj,
                                                                 const float *__restrict__ projf, const int *__restrict__ nsol,
                                                                 int maxsol, double eps, int *__restrict__ counts,
-                                                                unsigned long long *__restrict__ mask, int words_per_pose)
+                                                                unsigned long long *__restrict__ mask, int words_per_pose, int spb)
 {
     constexpr int KC = SCREEN_KC;
     __shared__ int s_cnt[SCORE_SPB];
     __shared__ int s_list[SCORE_SPB];
     __shared__ int s_wave_n[SCORE_THREADS / 64];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int slot0 = blockIdx.x * SCORE_SPB;
+    const int slot0 = blockIdx.x * spb;
     {
         const int slot = slot0 + tid;
-        bool valid = slot < nslots;
+        bool valid = tid < spb && slot < nslots;
         if (valid && nsol) valid = (slot % maxsol) < nsol[slot / maxsol];
         s_cnt[tid] = 0;
         const unsigned long long b = __ballot(valid);
@@ -613,7 +615,7 @@ __global__ __launch_bounds__(SCORE_THREADS) void k_score_screen(query_dev q, int
         }
     }
     __syncthreads();
-    if (slot0 + tid < nslots) counts[slot0 + tid] = s_cnt[tid];
+    if (tid < spb && slot0 + tid < nslots) counts[slot0 + tid] = s_cnt[tid];
 }
 
 // ------------------------------------------------------------------------------------------
@@ -621,20 +623,21 @@ __global__ __launch_bounds__(SCORE_THREADS) void k_score_screen(query_dev q, int
 // coverage boxes of the pose's inliers into a private bitmap in global memory and counts
 // the set bits.  all_matches != 0 paints every correspondence (the match_area map).
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_coverage(query_dev q, int nposes, const double *__restrict__ proj, double eps, int all_matches,
-                                                  unsigned int *__restrict__ bitmaps, int words_per_row, long long *__restrict__ areas)
+// With `slots` the i-th pose is proj[slots[i]] (candidate poses picked out of a chunk).
+// gridDim.y blocks share one pose (bitmaps and areas are zeroed by the host beforehand):
+// k_coverage paints, k_coverage_count adds up the set bits.
+__global__ __launch_bounds__(256) void k_coverage(query_dev q, int nposes, const double *__restrict__ proj, const int *__restrict__ slots,
+                                                  double eps, int all_matches, unsigned int *__restrict__ bitmaps, int words_per_row)
 {
     const int pose = blockIdx.x;
     if (pose >= nposes) return;
     const int tid = threadIdx.x;
     const size_t nwords = (size_t)words_per_row * q.height;
     unsigned int *bm = bitmaps + (size_t)pose * nwords;
-    for (size_t i = tid; i < nwords; i += blockDim.x) bm[i] = 0u;
-    __syncthreads();
     const double hw = (double)q.width / 2.0, hh = (double)q.height / 2.0;
-    const double *P = proj + (size_t)pose * 12;
+    const double *P = proj + (size_t)(slots ? slots[pose] : pose) * 12;
     const int cover = (int)ceilf((float)q.width / 20.0f);
-    for (int i = tid; i < q.n; i += blockDim.x) {
+    for (int i = blockIdx.y * blockDim.x + tid; i < q.n; i += gridDim.y * blockDim.x) {
         bool in = true;
         if (!all_matches) {
             const double X = q.X[i], Y = q.Y[i], Z = q.Z[i];
@@ -661,14 +664,22 @@ __global__ __launch_bounds__(256) void k_coverage(query_dev q, int nposes, const
             }
         }
     }
-    __syncthreads();
-    __shared__ long long s_sum[256];
-    long long a = 0;
-    for (size_t i = tid; i < nwords; i += blockDim.x) a += __popc(bm[i]);
+}
+
+__global__ __launch_bounds__(256) void k_coverage_count(int nposes, size_t nwords, const unsigned int *__restrict__ bitmaps,
+                                                        unsigned long long *__restrict__ areas)
+{
+    const int pose = blockIdx.x;
+    if (pose >= nposes) return;
+    const int tid = threadIdx.x;
+    const unsigned int *bm = bitmaps + (size_t)pose * nwords;
+    __shared__ unsigned long long s_sum[256];
+    unsigned long long a = 0;
+    for (size_t i = (size_t)blockIdx.y * blockDim.x + tid; i < nwords; i += (size_t)gridDim.y * blockDim.x) a += __popc(bm[i]);
     s_sum[tid] = a;
     __syncthreads();
     for (int o = 128; o > 0; o >>= 1) { if (tid < o) s_sum[tid] += s_sum[tid + o]; __syncthreads(); }
-    if (tid == 0) areas[pose] = s_sum[0];
+    if (tid == 0 && s_sum[0]) atomicAdd(&areas[pose], s_sum[0]);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -33,6 +33,7 @@ struct pose_amd_ctx {
     double focal = 0;
     dev_buf kx, ky, X, Y, Z, lindex, cam_off, cam_ids, gain;
     bool has_lindex = false, has_cam = false;
+    int64_t area_all = -1;         // coverage area of all matches (query_processor.cpp:154-169), -1 = not computed yet
     float xmax = 0, umax = 0;      // largest |coordinate| and largest |centred keypoint coordinate| of the query
     bool score_fp64_only = false;  // POSE_AMD_SCORE=fp64: skip the float32 screen (for A/B checks)
     dev_buf projf;
@@ -111,10 +112,14 @@ static int launch_p4pf(pose_amd_ctx *ctx, uint32_t count, const uint32_t *sample
     int rc;
     if ((rc = ensure(ctx, ctx->arows, (size_t)count * P4PF_TAIL * 8)) || (rc = ensure(ctx, ctx->pstatus, (size_t)count * 4))) return rc;
     const query_dev q = make_query(ctx);
-    const int nbatch = cdiv(count, ELIM_BATCH);
-    const int max_blocks = (ctx->cus ? ctx->cus : 256) * 8;
-    hipLaunchKernelGGL(k_p4pf_elim, dim3(std::min(nbatch, max_blocks)), dim3(64), 0, ctx->stream, q, count, samples, m2d, M3D,
-                       (double *)ctx->arows.p, (int *)ctx->pstatus.p);
+    // 32 systems per block amortise the coefficient phase; launches too small to give every
+    // wave slot of the chip a block that way use smaller (even) batches
+    const int slots = (ctx->cus ? ctx->cus : 256) * 8;
+    int batch = 2 * cdiv(cdiv(count, slots), 2);
+    batch = std::max(2, std::min(batch, ELIM_BATCH));
+    const int nbatch = cdiv(count, batch);
+    hipLaunchKernelGGL(k_p4pf_elim, dim3(std::min(nbatch, slots)), dim3(64), 0, ctx->stream, q, count, samples, m2d, M3D,
+                       (double *)ctx->arows.p, (int *)ctx->pstatus.p, batch);
     HIPCHK(ctx, hipGetLastError());
     HIPCHK(ctx, hipEventRecord(ctx->ev[4], ctx->stream));     // end of the elimination kernel, for the per-kernel timing
     hipLaunchKernelGGL(k_p4pf_finish, dim3(cdiv(count, 64)), dim3(64), 0, ctx->stream, q, count, samples, m2d, M3D,
@@ -287,6 +292,7 @@ int pose_amd_set_query(pose_amd_ctx *ctx, int n, const float *kx, const float *k
     ctx->has_cam = false;
     ctx->hyp_count = 0;
     ctx->have_best = false;
+    ctx->area_all = -1;
     return pose_amd_synchronize(ctx);
 }
 
@@ -335,7 +341,11 @@ static int launch_score(pose_amd_ctx *ctx, int nslots, const double *proj_dev, c
                         int *counts_dev, unsigned long long *mask_dev, int words_per_pose)
 {
     const query_dev q = make_query(ctx);
-    const dim3 grid(cdiv(nslots, SCORE_SPB)), block(SCORE_THREADS);
+    // slots per block: as many as possible (each block streams the correspondences once for all
+    // its poses) while small launches still get about four blocks per compute unit
+    int spb = SCORE_SPB;
+    while (spb > 8 && cdiv(nslots, spb) < (ctx->cus ? ctx->cus : 256) * 4) spb >>= 1;
+    const dim3 grid(cdiv(nslots, spb)), block(SCORE_THREADS);
     if (!ctx->score_fp64_only) {
         int rc;
         if ((rc = ensure(ctx, ctx->projf, (size_t)nslots * 128))) return rc;
@@ -343,19 +353,19 @@ static int launch_score(pose_amd_ctx *ctx, int nslots, const double *proj_dev, c
                            (float *)ctx->projf.p);
         if (mask_dev)
             hipLaunchKernelGGL((k_score_screen<true>), grid, block, 0, ctx->stream, q, nslots, proj_dev, (const float *)ctx->projf.p,
-                               nsol_dev, maxsol, eps, counts_dev, mask_dev, words_per_pose);
+                               nsol_dev, maxsol, eps, counts_dev, mask_dev, words_per_pose, spb);
         else
             hipLaunchKernelGGL((k_score_screen<false>), grid, block, 0, ctx->stream, q, nslots, proj_dev, (const float *)ctx->projf.p,
-                               nsol_dev, maxsol, eps, counts_dev, (unsigned long long *)nullptr, 0);
+                               nsol_dev, maxsol, eps, counts_dev, (unsigned long long *)nullptr, 0, spb);
         HIPCHK(ctx, hipGetLastError());
         return POSE_AMD_OK;
     }
     if (mask_dev)
         hipLaunchKernelGGL((k_score<4, true>), grid, block, 0, ctx->stream, q, nslots, proj_dev, nsol_dev, maxsol, eps, counts_dev,
-                           mask_dev, words_per_pose);
+                           mask_dev, words_per_pose, spb);
     else
         hipLaunchKernelGGL((k_score<4, false>), grid, block, 0, ctx->stream, q, nslots, proj_dev, nsol_dev, maxsol, eps, counts_dev,
-                           (unsigned long long *)nullptr, 0);
+                           (unsigned long long *)nullptr, 0, spb);
     HIPCHK(ctx, hipGetLastError());
     return POSE_AMD_OK;
 }
@@ -382,19 +392,27 @@ int pose_amd_score_batch(pose_amd_ctx *ctx, int nposes, const double *P, double 
 }
 
 // areas of `nposes` device-resident projection matrices -> host
-static int coverage_dev(pose_amd_ctx *ctx, int nposes, const double *proj_dev, double eps, int all_matches, int64_t *areas_host)
+static int coverage_dev(pose_amd_ctx *ctx, int nposes, const double *proj_dev, double eps, int all_matches, int64_t *areas_host,
+                        const int *slots_dev = nullptr)
 {
     const query_dev q = make_query(ctx);
     const int wpr = (ctx->width + 31) / 32;
     const size_t words = (size_t)wpr * ctx->height;
     int rc;
     if ((rc = ensure(ctx, ctx->areas, (size_t)nposes * 8))) return rc;
+    HIPCHK(ctx, hipMemsetAsync(ctx->areas.p, 0, (size_t)nposes * 8, ctx->stream));
     const int chunk_max = 256;
     for (int p0 = 0; p0 < nposes; p0 += chunk_max) {
         const int cn = nposes - p0 < chunk_max ? nposes - p0 : chunk_max;
+        // few poses: several blocks share one pose so that painting thousands of boxes (the
+        // all-matches map, a pose with many inliers) does not run on a single compute unit
+        const int split = cn >= 128 ? 1 : std::min(32, std::max(1, cdiv(ctx->n, 256)));
         if ((rc = ensure(ctx, ctx->bitmaps, (size_t)cn * words * 4))) return rc;
-        hipLaunchKernelGGL(k_coverage, dim3(cn), dim3(256), 0, ctx->stream, q, cn, proj_dev + (size_t)p0 * 12, eps, all_matches,
-                           (unsigned int *)ctx->bitmaps.p, wpr, (long long *)ctx->areas.p + p0);
+        HIPCHK(ctx, hipMemsetAsync(ctx->bitmaps.p, 0, (size_t)cn * words * 4, ctx->stream));
+        hipLaunchKernelGGL(k_coverage, dim3(cn, split), dim3(256), 0, ctx->stream, q, cn, slots_dev ? proj_dev : proj_dev + (size_t)p0 * 12,
+                           slots_dev ? slots_dev + p0 : nullptr, eps, all_matches, (unsigned int *)ctx->bitmaps.p, wpr);
+        hipLaunchKernelGGL(k_coverage_count, dim3(cn, split), dim3(256), 0, ctx->stream, cn, words, (const unsigned int *)ctx->bitmaps.p,
+                           (unsigned long long *)ctx->areas.p + p0);
         HIPCHK(ctx, hipGetLastError());
     }
     if ((rc = download(ctx, areas_host, ctx->areas.p, (size_t)nposes * 8))) return rc;
@@ -537,8 +555,12 @@ int pose_amd_ransac_run(pose_amd_ctx *ctx, const pose_amd_params *prm, pose_amd_
     const bool coverage = prm->select_mode == POSE_AMD_SELECT_COVERAGE;
     int64_t area_all = 0;
     if (coverage) {
-        double dummy[12] = {0};
-        if ((rc = upload(ctx, ctx->in1, dummy, 96)) || (rc = coverage_dev(ctx, 1, (const double *)ctx->in1.p, prm->eps, 1, &area_all))) return rc;
+        if (ctx->area_all < 0) {        // depends on the query only
+            double dummy[12] = {0};
+            if ((rc = upload(ctx, ctx->in1, dummy, 96)) || (rc = coverage_dev(ctx, 1, (const double *)ctx->in1.p, prm->eps, 1, &ctx->area_all)))
+                return rc;
+        }
+        area_all = ctx->area_all;
     }
     const long long cover = (long long)std::ceil((float)ctx->width / 20.0f);
     const long long box = (long long)(2 * (cover / 2)) * (2 * (cover / 2));   // largest area one coverage box can add
@@ -578,7 +600,7 @@ int pose_amd_ransac_run(pose_amd_ctx *ctx, const pose_amd_params *prm, pose_amd_
             if ((rc = download(ctx, h_nsol.data(), ctx->nsol.p, (size_t)hc * 4)) ||
                 (rc = download(ctx, h_counts.data(), ctx->counts.p, nslots * 4)) || (rc = pose_amd_synchronize(ctx)))
                 return rc;
-            const int BATCH = 64;
+            const int BATCH = 256;
             areas.resize(BATCH);
             size_t s = 0;
             while (!done && s < nslots) {
@@ -590,11 +612,10 @@ int pose_amd_ransac_run(pose_amd_ctx *ctx, const pose_amd_params *prm, pose_amd_
                     ++scan;
                 }
                 if (!cand.empty()) {
-                    if ((rc = ensure(ctx, ctx->in0, cand.size() * 96))) return rc;
-                    for (size_t i = 0; i < cand.size(); ++i)
-                        HIPCHK(ctx, hipMemcpyAsync((char *)ctx->in0.p + i * 96, (const char *)ctx->proj.p + (size_t)cand[i] * 96, 96,
-                                                   hipMemcpyDeviceToDevice, ctx->stream));
-                    if ((rc = coverage_dev(ctx, (int)cand.size(), (const double *)ctx->in0.p, prm->eps, 0, areas.data()))) return rc;
+                    if ((rc = upload(ctx, ctx->in0, cand.data(), cand.size() * 4))) return rc;
+                    if ((rc = coverage_dev(ctx, (int)cand.size(), (const double *)ctx->proj.p, prm->eps, 0, areas.data(),
+                                           (const int *)ctx->in0.p)))
+                        return rc;
                 }
                 size_t ci = 0;
                 for (size_t t = s; t < scan; ++t) {                  // replay in order

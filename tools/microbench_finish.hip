@@ -79,7 +79,7 @@ int main(int argc, char **argv)
     const int nbatch = (n + ELIM_BATCH - 1) / ELIM_BATCH;
     for (int rep = 0; rep < 2; ++rep) {
         CHECK(hipEventRecord(e0));
-        k_p4pf_elim<<<nbatch < 2048 ? nbatch : 2048, 64>>>(q, n, nullptr, dm, dM, dA, dst);
+        k_p4pf_elim<<<nbatch < 2048 ? nbatch : 2048, 64>>>(q, n, nullptr, dm, dM, dA, dst, ELIM_BATCH);
         CHECK(hipEventRecord(e1));
         CHECK(hipDeviceSynchronize());
     }
