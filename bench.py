@@ -47,7 +47,9 @@ def main():
     ap.add_argument("--queries", type=int, default=800)
     ap.add_argument("--budget", type=int, default=10000, help="dubrovnik: hypotheses per query")
     ap.add_argument("--early-exit", action="store_true", help="dubrovnik: the reference's loop (coverage quality, stop at 12 inliers)")
-    ap.add_argument("--host-threads", type=int, default=4, help="dubrovnik: contexts (streams) per GPU driven concurrently")
+    ap.add_argument("--advanced", action="store_true",
+                    help="dubrovnik: configs[3], the advanced processor (co-occurrence sampling over camera sets, 100 steps, no early exit)")
+    ap.add_argument("--host-threads", type=int, default=8, help="dubrovnik: contexts (streams) per GPU driven concurrently")
     args = ap.parse_args()
     if args.workload == "dubrovnik":
         return bench_dubrovnik(args)
@@ -167,7 +169,9 @@ def bench_dubrovnik(args):
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    from pose_estimation_amd import Context, shard, synth, SELECT_INLIERS, SELECT_COVERAGE, SAMPLE_BASIC
+    from pose_estimation_amd import Context, shard, synth, SELECT_INLIERS, SELECT_COVERAGE, SAMPLE_BASIC, SAMPLE_ADVANCED
+    if args.advanced:
+        args.budget, args.early_exit = 100, False
     with open(os.path.join(ROOT, "tests", "golden", "dubrovnik_queries.json")) as f:
         shapes = json.load(f)["queries"]
     nq = args.queries
@@ -180,17 +184,21 @@ def bench_dubrovnik(args):
         w, h, f = shapes[qi % len(shapes)]
         q = synth.make_query(int(sizes[qi]), float(fracs[qi]), 3000 + qi, width=w, height=h, focal=f if f > 0 else 0.9 * max(w, h),
                              known_focal=f > 0)
+        if args.advanced:
+            synth.add_camsets(q, seed=4000 + qi)
         queries.append((qi, q))
     T = max(1, args.host_threads)
     ctxs = [Context(local_rank) for _ in range(T)]
-    select = SELECT_COVERAGE if args.early_exit else SELECT_INLIERS
+    select = SELECT_COVERAGE if (args.early_exit or args.advanced) else SELECT_INLIERS
 
     def run_part(t):
         ctx = ctxs[t]
         out = []
         for qi, q in queries[t::T]:
             ctx.set_query(q["kx"], q["ky"], q["X"], q["Y"], q["Z"], q["width"], q["height"], q["focal"])
-            ctx.sample(SAMPLE_BASIC, 3000, qi, 0, args.budget, export=False)
+            if args.advanced:
+                ctx.set_camsets(q["cam_off"], q["cam_ids"])
+            ctx.sample(SAMPLE_ADVANCED if args.advanced else SAMPLE_BASIC, 3000, qi, 0, args.budget, export=False)
             r = ctx.ransac_run(select, 0.5, early_exit=args.early_exit)
             out.append((qi, r["steps"], r["inliers"], float(np.linalg.norm(r["C"] - q["C_true"])) if r["found"] else float("inf")))
         return out
@@ -228,14 +236,15 @@ def bench_dubrovnik(args):
     if rank == 0:
         steps_total = sum(r[1] for r in res)
         located = sum(1 for r in res if r[3] < 2.0)
-        out = {"metric": "queries/sec (Dubrovnik-shaped batch, basic RANSAC)", "value": round(nq * args.steps / dt, 1), "unit": "queries/s",
+        out = {"metric": "queries/sec (Dubrovnik-shaped batch, %s RANSAC)" % ("advanced" if args.advanced else "basic"), "value": round(nq * args.steps / dt, 1), "unit": "queries/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
                "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-               "config": {"workload": "BASELINE configs[2]: %d Dubrovnik6K-shaped queries (real image sizes, %d known / %d unknown focal), "
+               "config": {"workload": "BASELINE configs[2/3]: %d Dubrovnik6K-shaped queries (real image sizes, %d known / %d unknown focal), "
                                       "4000-6000 matches, 10-40%% inliers, %s"
                                       % (nq, sum(1 for i in range(nq) if shapes[i % len(shapes)][2] > 0),
                                          sum(1 for i in range(nq) if shapes[i % len(shapes)][2] == 0),
-                                         "reference loop: coverage quality, early exit, <= %d steps" % args.budget if args.early_exit
+                                         "advanced processor: co-occurrence sampling over camera sets, 100 steps, coverage quality" if args.advanced
+                                         else "reference loop: coverage quality, early exit, <= %d steps" % args.budget if args.early_exit
                                          else "fixed budget of %d hypotheses per query, inlier-count selection" % args.budget),
                           "parallelism": "queries partitioned over %d GPU(s), %d host threads (contexts) per GPU" % (world, T),
                           "hypotheses_per_s": round(steps_total * args.steps / dt, 1),

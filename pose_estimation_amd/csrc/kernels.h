@@ -56,57 +56,120 @@ __global__ void k_sample_basic(query_dev q, int m, uint64_t seed, uint32_t query
 // query_processor_advanced.cpp:329-440: co-occurrence prioritised accept/reject chain.
 // gain[c] = 1/(1+exp(-(c/5))) is tabulated by the host so that host and device agree bit
 // for bit.  status[i] = 0 ok, 1 = camera set larger than MAXCAM met (tuple invalid).
-__global__ void k_sample_advanced(query_dev q, int m, uint64_t seed, uint32_t query_id, uint32_t hyp_begin,
-                                  uint32_t hyp_count, const double *__restrict__ gain, uint32_t *__restrict__ samples,
-                                  int *__restrict__ status)
+//
+// One hypothesis per wave.  The chain is sequential (a candidate is judged against the camera
+// set intersection of the picks accepted so far), but candidates come from counter-based
+// streams, so the next 64 candidates can be drawn and classified at once, one per lane, and the
+// first event in stream order -- an acceptance, or the 31st empty intersection that restarts the
+// tuple -- found with ballots.  Which random numbers a candidate consumes depends only on the
+// candidates before it (one index draw each, one probability draw per ratio test), so the
+// tuples equal those of the one-candidate-at-a-time loop.
+constexpr int SAMPLE_ADV_WAVES = 4;
+
+__device__ __forceinline__ uint32_t draw_at(uint64_t seed, uint32_t query_id, uint32_t hyp, uint32_t stream, uint32_t pos)
 {
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= hyp_count) return;
-    draw_stream di(seed, query_id, hyp_begin + t, 0), dp(seed, query_id, hyp_begin + t, 1);
-    uint32_t inter[MAXCAM], check[MAXCAM], sel[4] = {NO_INDEX, NO_INDEX, NO_INDEX, NO_INDEX};
+    uint32_t buf[4];
+    philox4x32_10(hyp, pos >> 2, query_id, stream, (uint32_t)seed, (uint32_t)(seed >> 32), buf);
+    return buf[pos & 3u];
+}
+
+__global__ __launch_bounds__(64 * SAMPLE_ADV_WAVES) void k_sample_advanced(query_dev q, int m, uint64_t seed, uint32_t query_id,
+                                                                            uint32_t hyp_begin, uint32_t hyp_count,
+                                                                            const double *__restrict__ gain, uint32_t *__restrict__ samples,
+                                                                            int *__restrict__ status)
+{
+    __shared__ uint32_t s_inter[SAMPLE_ADV_WAVES][MAXCAM];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t t = blockIdx.x * SAMPLE_ADV_WAVES + wave;
+    if (t >= hyp_count) return;                          // whole waves leave together
+    uint32_t *inter = s_inter[wave];
+    const uint32_t hyp = hyp_begin + t;
+    const unsigned long long lt = (1ull << lane) - 1ull;  // lanes before this one
+    uint32_t di = 0, dp = 0;                             // draws consumed from the index / probability streams
+    uint32_t sel[4] = {NO_INDEX, NO_INDEX, NO_INDEX, NO_INDEX}, lsel[4] = {0, 0, 0, 0};
     uint32_t ninter = 0;
     int nsel = 0, zero_check_count = 0, bad = 0;
     const int zero_check_limit = 200;
-    for (int i = 0; i < m; ++i) {
-        bool valid = false;
-        int zero_check = 0;
-        while (!valid) {
-            uint32_t idx, cb, ce;
-            do {
-                idx = draw_index(di, (uint32_t)q.n);
-                cb = q.cam_off[idx]; ce = q.cam_off[idx + 1];
-                if (ce - cb > (uint32_t)MAXCAM) { bad = 1; ce = cb + MAXCAM; }
-                if (i == 0) { ninter = ce - cb; for (uint32_t c = 0; c < ninter; ++c) inter[c] = q.cam_ids[cb + c]; }
-            } while (i == 0 && ce - cb < 5);
-            valid = true;
+    int i = 0, zero_check = 0;
+    while (i < m) {
+        const uint32_t idx = (uint32_t)(((uint64_t)draw_at(seed, query_id, hyp, 0, di + lane) * (uint32_t)q.n) >> 32);
+        uint32_t cb = q.cam_off[idx], ce = q.cam_off[idx + 1];
+        if (ce - cb > (uint32_t)MAXCAM) { bad = 1; ce = cb + MAXCAM; }
+        int ev;                                          // lane of the first event
+        bool restart = false;
+        uint32_t ncheck = 0;
+        if (i == 0) {
+            // first pick: redraw until the candidate is seen by >= 5 cameras (:350-359)
+            const unsigned long long ok = __ballot(ce - cb >= 5);
+            if (!ok) { di += 64; continue; }
+            ev = __builtin_ctzll(ok);
+        } else {
             const uint32_t l = lindex_of(q, idx);
-            for (int j = 0; j < nsel; ++j) if (lindex_of(q, sel[j]) == l) valid = false;
-            uint32_t ncheck = 0;
-            if (valid && i > 0) {
+            bool dup = false;
+            for (int j = 0; j < nsel; ++j) dup = dup || lsel[j] == l;
+            if (!dup) {
                 uint32_t p = cb, r = 0;
                 while (p < ce && r < ninter) {
                     const uint32_t a = q.cam_ids[p], b = inter[r];
-                    if (a < b) ++p; else if (b < a) ++r; else { check[ncheck++] = b; ++p; ++r; }
-                }
-                if (ncheck == 0 && zero_check_count <= zero_check_limit) {
-                    zero_check++;
-                    valid = false;
-                } else {
-                    const uint32_t mn = ninter < ce - cb ? ninter : ce - cb;
-                    float ratio = (float)ncheck / (float)mn;
-                    ratio = (float)((double)ratio * gain[ncheck]);
-                    const float temp = (float)(dp.next() >> 8) * (1.0f / 16777216.0f);
-                    if (zero_check_count > zero_check_limit) ratio = 1.0f;
-                    if (ratio > temp) { valid = true; ninter = ncheck; for (uint32_t c = 0; c < ncheck; ++c) inter[c] = check[c]; }
-                    else valid = false;
+                    if (a < b) ++p; else if (b < a) ++r; else { ++ncheck; ++p; ++r; }
                 }
             }
-            if (valid) sel[nsel++] = idx;
-            if (zero_check > 30) { i = -1; nsel = 0; ninter = 0; valid = true; zero_check_count++; }
+            const bool empty = !dup && ncheck == 0 && zero_check_count <= zero_check_limit;   // zero_check++ (:383-386)
+            const bool test = !dup && !empty;                                                 // consumes one probability draw
+            const unsigned long long bE = __ballot(empty), bT = __ballot(test);
+            bool accept = false;
+            if (test) {
+                const uint32_t mn = ninter < ce - cb ? ninter : ce - cb;
+                float ratio = (float)ncheck / (float)mn;
+                ratio = (float)((double)ratio * gain[ncheck]);
+                const float temp = (float)(draw_at(seed, query_id, hyp, 1, dp + (uint32_t)__popcll(bT & lt)) >> 8) * (1.0f / 16777216.0f);
+                if (zero_check_count > zero_check_limit) ratio = 1.0f;
+                accept = ratio > temp;
+            }
+            const unsigned long long bA = __ballot(accept);
+            // the candidate whose empty intersection is number 31 of this pick restarts the tuple (:425-435)
+            const unsigned long long bR = __ballot(empty && zero_check + __popcll(bE & lt) + 1 > 30);
+            const int ea = bA ? __builtin_ctzll(bA) : 64, er = bR ? __builtin_ctzll(bR) : 64;
+            if (ea == 64 && er == 64) {
+                di += 64; dp += (uint32_t)__popcll(bT); zero_check += __popcll(bE);
+                continue;
+            }
+            restart = er < ea;
+            ev = restart ? er : ea;
+            const unsigned long long upto = ev == 63 ? ~0ull : ((1ull << (ev + 1)) - 1ull);
+            dp += (uint32_t)__popcll(bT & upto);
         }
+        di += (uint32_t)ev + 1;
+        if (restart) {
+            i = 0; nsel = 0; ninter = 0; zero_check = 0; zero_check_count++;
+            continue;
+        }
+        // the accepted candidate becomes pick i; the running intersection becomes its check set
+        const uint32_t aidx = (uint32_t)__builtin_amdgcn_readlane((int)idx, ev);
+        const uint32_t acb = (uint32_t)__builtin_amdgcn_readlane((int)cb, ev), ace = (uint32_t)__builtin_amdgcn_readlane((int)ce, ev);
+        if (i == 0) {
+            ninter = ace - acb;
+            for (uint32_t c = lane; c < ninter; c += 64) inter[c] = q.cam_ids[acb + c];
+        } else {
+            if (lane == ev) {
+                uint32_t p = cb, r = 0, w = 0;
+                while (p < ce && r < ninter) {
+                    const uint32_t a = q.cam_ids[p], b = inter[r];
+                    if (a < b) ++p; else if (b < a) ++r; else { inter[w++] = b; ++p; ++r; }   // w <= r: in place
+                }
+            }
+            ninter = (uint32_t)__builtin_amdgcn_readlane((int)ncheck, ev);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        sel[nsel] = aidx; lsel[nsel] = lindex_of(q, aidx); ++nsel;
+        ++i; zero_check = 0;
     }
-    reinterpret_cast<uint4 *>(samples)[t] = make_uint4(sel[0], m > 1 ? sel[1] : NO_INDEX, m > 2 ? sel[2] : NO_INDEX, m > 3 ? sel[3] : NO_INDEX);
-    status[t] = bad;
+    const int any_bad = __ballot(bad != 0) != 0;
+    if (lane == 0) {
+        reinterpret_cast<uint4 *>(samples)[t] = make_uint4(sel[0], m > 1 ? sel[1] : NO_INDEX, m > 2 ? sel[2] : NO_INDEX, m > 3 ? sel[3] : NO_INDEX);
+        status[t] = any_bad;
+    }
 }
 
 // ------------------------------------------------------------------------------------------

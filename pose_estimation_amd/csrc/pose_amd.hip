@@ -460,7 +460,7 @@ int pose_amd_sample(pose_amd_ctx *ctx, int sample_mode, uint64_t seed, uint32_t 
                            hyp_count, (uint32_t *)ctx->samples.p);
     } else {
         if ((rc = ensure(ctx, ctx->sample_status, (size_t)hyp_count * 4))) return rc;
-        hipLaunchKernelGGL(k_sample_advanced, dim3(cdiv(hyp_count, 64)), dim3(64), 0, ctx->stream, q, m, seed, query_id, hyp_begin,
+        hipLaunchKernelGGL(k_sample_advanced, dim3(cdiv(hyp_count, SAMPLE_ADV_WAVES)), dim3(64 * SAMPLE_ADV_WAVES), 0, ctx->stream, q, m, seed, query_id, hyp_begin,
                            hyp_count, (const double *)ctx->gain.p, (uint32_t *)ctx->samples.p, (int *)ctx->sample_status.p);
     }
     HIPCHK(ctx, hipGetLastError());

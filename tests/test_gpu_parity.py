@@ -440,3 +440,26 @@ def test_score_screen_equals_float64_kernel(ctx):
                 c0, m0 = ref_ctx.score_batch(P, eps, want_masks=True)
                 assert np.array_equal(c1, c0) and np.array_equal(m1, m0)
                 assert c0.max() > 0.1 * n and c0.min() < 0.05 * n
+
+
+def test_ransac_large_query_config5_shape(ctx):
+    """BASELINE config 5 in miniature: 100 000 matches, 1 % inliers, a hypothesis range split in
+    two halves whose packed keys are max-reduced (what the ranks do) equals the whole range."""
+    from pose_estimation_amd import shard
+    n = 100000
+    q = synth.make_query(n, 0.01, 5)
+    upload(ctx, q)
+    total = 96
+    samples = ctx.sample(SAMPLE_BASIC, 5005, 0, 0, total)
+    whole = ctx.ransac_run(SELECT_INLIERS, 0.5, early_exit=False, hyp_count=total, want_per_hyp=True)
+    o = O.ransac(q["kx"], q["ky"], q["X"], q["Y"], q["Z"], q["width"], q["height"], 0.0, samples, select_coverage=False,
+                 early_exit=False, max_steps=total)
+    assert (whole["best_hyp"], whole["inliers"]) == (o["best_step"], o["hyposet"])
+    keys = []
+    for r in range(2):
+        b, e = shard.hypothesis_shard(total, r, 2)
+        part = ctx.sample(SAMPLE_BASIC, 5005, 0, b, e - b)
+        assert np.array_equal(part, samples[b:e])                      # any rank can draw any range
+        res = ctx.ransac_run(SELECT_INLIERS, 0.5, early_exit=False)
+        keys.append(shard.pack_key(res["inliers"], b + res["best_hyp"]))
+    assert shard.unpack_key(max(keys)) == (whole["inliers"], whole["best_hyp"])
