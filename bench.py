@@ -42,6 +42,8 @@ def main():
     ap.add_argument("--inlier-frac", type=float, default=0.10)
     ap.add_argument("--cpu-hyps", type=int, default=0, help="CPU baseline sample size (0 = auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
+                    help="process-group backend; gloo (CPU tensors) lets several ranks rehearse on one GPU")
     ap.add_argument("--workload", choices=["single", "dubrovnik"], default="single",
                     help="single: BASELINE configs[1] (default, the headline line); dubrovnik: configs[2], 800 queries sharded by query")
     ap.add_argument("--queries", type=int, default=800)
@@ -59,16 +61,22 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     import torch
     dist = None
+    ndev = max(1, torch.cuda.device_count())
+    dev_index = local_rank % ndev
+    red_dev = f"cuda:{dev_index}" if args.backend == "nccl" else "cpu"
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        torch.cuda.set_device(dev_index)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group("gloo")
     elif args.gpus > 1:
         print("bench.py: --gpus > 1 must be launched through torch.distributed.run", file=sys.stderr)
         return 2
 
     from pose_estimation_amd import Context, shard, synth, SELECT_INLIERS, SAMPLE_BASIC
-    ctx = Context(local_rank)
+    ctx = Context(dev_index)
     q = synth.make_query(args.matches, args.inlier_frac, seed=2)
     ctx.set_query(q["kx"], q["ky"], q["X"], q["Y"], q["Z"], q["width"], q["height"], 0.0)
     H = args.hyps
@@ -80,7 +88,7 @@ def main():
         if world > 1:
             # the only exchange of the hypothesis-sharded path: one packed (count, id) key
             gh = ((i * world + rank) * H + r["best_hyp"]) & shard.KEY_ID_MASK
-            r["global_best"] = shard.unpack_key(shard.reduce_best(shard.pack_key(r["inliers"], gh), dist, f"cuda:{local_rank}"))
+            r["global_best"] = shard.unpack_key(shard.reduce_best(shard.pack_key(r["inliers"], gh), dist, red_dev))
         return r
 
     def sync():
@@ -105,7 +113,7 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
+        t = torch.tensor([dt], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
@@ -166,10 +174,16 @@ def bench_dubrovnik(args):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     import torch
     dist = None
+    ndev = max(1, torch.cuda.device_count())
+    dev_index = local_rank % ndev
+    red_dev = f"cuda:{dev_index}" if args.backend == "nccl" else "cpu"
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        torch.cuda.set_device(dev_index)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group("gloo")
     from pose_estimation_amd import Context, shard, synth, SELECT_INLIERS, SELECT_COVERAGE, SAMPLE_BASIC, SAMPLE_ADVANCED
     if args.advanced:
         args.budget, args.early_exit = 100, False
@@ -189,7 +203,7 @@ def bench_dubrovnik(args):
             synth.add_camsets(q, seed=4000 + qi)
         queries.append((qi, q))
     T = max(1, args.host_threads)
-    ctxs = [Context(local_rank) for _ in range(T)]
+    ctxs = [Context(dev_index) for _ in range(T)]
     select = SELECT_COVERAGE if (args.early_exit or args.advanced) else SELECT_INLIERS
 
     def run_part(t):
@@ -228,7 +242,7 @@ def bench_dubrovnik(args):
         sync()
         dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
+        t = torch.tensor([dt], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
         stats = [None] * world
