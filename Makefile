@@ -12,7 +12,7 @@ FACADE_TEST := tests/cpp/facade_test
 all: $(LIB) oracle $(SHIM) $(FACADE_TEST)
 
 $(LIB): $(CSRC)/pose_amd.hip $(HDRS)
-	$(HIPCC) -O3 -std=c++17 --offload-arch=$(ARCH) -fPIC -shared -Wall -Wno-unused-function -o $@ $<
+	$(HIPCC) -O3 -std=c++17 --offload-arch=$(ARCH) -fPIC -shared -pthread -Wall -Wno-unused-function -o $@ $<
 
 # Host build of the per-lane eigen step, used only by the CPU tests.
 $(SHIM): tests/host_shim/eig_shim.hip $(HDRS)

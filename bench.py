@@ -51,7 +51,8 @@ def main():
     ap.add_argument("--early-exit", action="store_true", help="dubrovnik: the reference's loop (coverage quality, stop at 12 inliers)")
     ap.add_argument("--advanced", action="store_true",
                     help="dubrovnik: configs[3], the advanced processor (co-occurrence sampling over camera sets, 100 steps, no early exit)")
-    ap.add_argument("--host-threads", type=int, default=8, help="dubrovnik: contexts (streams) per GPU driven concurrently")
+    ap.add_argument("--python-threads", action="store_true", help="dubrovnik: drive the contexts from Python threads instead of pose_amd_ransac_batch")
+    ap.add_argument("--host-threads", type=int, default=16, help="dubrovnik: contexts (streams) per GPU driven concurrently")
     args = ap.parse_args()
     if args.workload == "dubrovnik":
         return bench_dubrovnik(args)
@@ -203,8 +204,13 @@ def bench_dubrovnik(args):
             synth.add_camsets(q, seed=4000 + qi)
         queries.append((qi, q))
     T = max(1, args.host_threads)
-    ctxs = [Context(dev_index) for _ in range(T)]
     select = SELECT_COVERAGE if (args.early_exit or args.advanced) else SELECT_INLIERS
+    # one pose_amd_ransac_batch call: T worker threads inside the library, one stream each
+    batched = not args.python_threads
+    os.environ["POSE_AMD_BATCH_LANES"] = str(T)
+    ctxs = [Context(dev_index) for _ in range(1 if batched else T)]
+    for i, (qi, q) in enumerate(queries):
+        q["query_id"] = qi
 
     def run_part(t):
         ctx = ctxs[t]
@@ -220,6 +226,12 @@ def bench_dubrovnik(args):
 
     def one_pass(pool):
         res = []
+        if batched:
+            rs = ctxs[0].ransac_batch([q for _, q in queries], SAMPLE_ADVANCED if args.advanced else SAMPLE_BASIC, seed=3000, budget=args.budget, select_mode=select,
+                                      early_exit=args.early_exit)
+            for (qi, q), r in zip(queries, rs):
+                res.append((qi, r["steps"], r["inliers"], float(np.linalg.norm(r["C"] - q["C_true"])) if r["found"] else float("inf")))
+            return res
         for part in pool.map(run_part, range(T)):
             res.extend(part)
         return res
@@ -261,7 +273,8 @@ def bench_dubrovnik(args):
                                          "advanced processor: co-occurrence sampling over camera sets, 100 steps, coverage quality" if args.advanced
                                          else "reference loop: coverage quality, early exit, <= %d steps" % args.budget if args.early_exit
                                          else "fixed budget of %d hypotheses per query, inlier-count selection" % args.budget),
-                          "parallelism": "queries partitioned over %d GPU(s), %d host threads (contexts) per GPU" % (world, T),
+                          "parallelism": "queries partitioned over %d GPU(s), %s" % (world, "%d worker threads / streams per GPU inside pose_amd_ransac_batch" % T if batched
+                                                                                      else "%d host threads (contexts) per GPU" % T),
                           "hypotheses_per_s": round(steps_total * args.steps / dt, 1),
                           "mean_steps_per_query": round(steps_total / max(len(res), 1), 1),
                           "queries_within_2_units_of_true_position": located}}

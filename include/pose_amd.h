@@ -124,6 +124,26 @@ int pose_amd_ransac_run(pose_amd_ctx *ctx, const pose_amd_params *params, pose_a
  * (fitted_matches, basic.cpp:224). */
 int pose_amd_best_mask(pose_amd_ctx *ctx, uint8_t *mask);
 
+/* ---- many queries (the loop over queries of benchmark.cpp:24-36) -------------------------- */
+typedef struct {
+    int n;                                   /* correspondences                                   */
+    const float *kx, *ky, *X, *Y, *Z;        /* as for pose_amd_set_query (host memory)           */
+    const uint32_t *lindex;                  /* may be NULL                                       */
+    const uint32_t *cam_off, *cam_ids;       /* camera sets, NULL unless sample_mode is ADVANCED  */
+    int width, height;
+    double focal;                            /* 0 => P4Pf                                         */
+    uint32_t query_id;                       /* selects the random stream, as in pose_amd_sample  */
+} pose_amd_query;
+
+/* Runs QueryProcessorBasic/Advanced::Process (from good_matches on) for `nq` independent
+ * queries: per query pose_amd_set_query [+ set_camsets] + pose_amd_sample(sample_mode, seed,
+ * query_id, 0, budget) + pose_amd_ransac_run(params), with identical results, but several
+ * internal worker threads (each with its own stream; count from POSE_AMD_BATCH_LANES, default 8)
+ * share the queries so that the small launches of different queries overlap on the device.
+ * results[nq].  The context's own resident query is not touched. */
+int pose_amd_ransac_batch(pose_amd_ctx *ctx, int nq, const pose_amd_query *queries, int sample_mode, uint64_t seed,
+                          uint32_t budget, const pose_amd_params *params, pose_amd_result *results);
+
 /* ---- measurement -------------------------------------------------------------------------- */
 /* Kernel time of the last pose_amd_ransac_run measured with HIP events on the context's
  * stream, summed over the call's chunks: ms[0] solve (all solver kernels), ms[1] score,

@@ -25,6 +25,14 @@ class Result(C.Structure):
                 ("best_hyp", C.c_uint32), ("best_sol", C.c_uint32), ("poses_scored", C.c_uint64)]
 
 
+class QueryDesc(C.Structure):
+    """pose_amd_query: one query of pose_amd_ransac_batch (host pointers)."""
+    _fields_ = [("n", C.c_int), ("kx", C.POINTER(C.c_float)), ("ky", C.POINTER(C.c_float)), ("X", C.POINTER(C.c_float)),
+                ("Y", C.POINTER(C.c_float)), ("Z", C.POINTER(C.c_float)), ("lindex", C.POINTER(C.c_uint32)),
+                ("cam_off", C.POINTER(C.c_uint32)), ("cam_ids", C.POINTER(C.c_uint32)), ("width", C.c_int), ("height", C.c_int),
+                ("focal", C.c_double), ("query_id", C.c_uint32)]
+
+
 _dp = C.POINTER(C.c_double)
 _fp = C.POINTER(C.c_float)
 _ip = C.POINTER(C.c_int)
@@ -53,6 +61,8 @@ SIGNATURES = {
     "pose_amd_set_samples": (C.c_int, [_ctx, _up, C.c_uint32]),
     "pose_amd_ransac_run": (C.c_int, [_ctx, C.POINTER(Params), C.POINTER(Result), _ip, _ip]),
     "pose_amd_best_mask": (C.c_int, [_ctx, _u8]),
+    "pose_amd_ransac_batch": (C.c_int, [_ctx, C.c_int, C.POINTER(QueryDesc), C.c_int, C.c_uint64, C.c_uint32, C.POINTER(Params),
+                                        C.POINTER(Result)]),
     "pose_amd_last_timing": (C.c_int, [_ctx, C.POINTER(C.c_float)]),
 }
 

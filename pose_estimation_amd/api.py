@@ -180,6 +180,36 @@ class Context:
             out["nsol"], out["counts"] = nsol, counts
         return out
 
+    def ransac_batch(self, queries, sample_mode=SAMPLE_BASIC, seed=0, budget=10000, select_mode=SELECT_COVERAGE, eps=0.5,
+                     early_exit=True, inlier_divisor=10, inlier_absolute=12):
+        """Process for many independent queries in one call.  `queries`: dicts with kx, ky, X, Y, Z,
+        width, height, focal (0 = unknown) and optionally lindex, cam_off, cam_ids, query_id
+        (default: position in the list).  Returns one result dict per query, equal to what
+        set_query + sample(sample_mode, seed, query_id, 0, budget) + ransac_run give."""
+        from ._lib import QueryDesc
+        nq = len(queries)
+        descs = (QueryDesc * max(nq, 1))()
+        keep = []
+        for i, q in enumerate(queries):
+            arrs = [_f32(q[k]) for k in ("kx", "ky", "X", "Y", "Z")]
+            li = _u32(q["lindex"]) if q.get("lindex") is not None else None
+            co = _u32(q["cam_off"]) if q.get("cam_off") is not None else None
+            ci = _u32(q["cam_ids"]) if q.get("cam_ids") is not None else None
+            keep.append((arrs, li, co, ci))
+            d = descs[i]
+            d.n = len(arrs[0])
+            d.kx, d.ky, d.X, d.Y, d.Z = (_ptr(a, _lib._fp) for a in arrs)
+            d.lindex, d.cam_off, d.cam_ids = _ptr(li, _lib._up), _ptr(co, _lib._up), _ptr(ci, _lib._up)
+            d.width, d.height, d.focal = int(q["width"]), int(q["height"]), float(q["focal"])
+            d.query_id = int(q.get("query_id", i))
+        prm = Params(int(select_mode), float(eps), int(bool(early_exit)), int(inlier_divisor), int(inlier_absolute))
+        res = (Result * max(nq, 1))()
+        self._chk(self._lib.pose_amd_ransac_batch(self._h, nq, descs, int(sample_mode), int(seed), int(budget), C.byref(prm), res),
+                  "ransac_batch")
+        return [dict(found=r.found, focal=r.focal, C=np.array(r.C[:]), Rc=np.array(r.Rc[:]).reshape(3, 3), inliers=r.inliers,
+                     area_fit=r.area_fit, area_all=r.area_all, steps=r.steps, best_hyp=r.best_hyp, best_sol=r.best_sol,
+                     poses_scored=r.poses_scored) for r in res[:nq]]
+
     def best_mask(self):
         m = np.zeros(self.n, dtype=np.uint8)
         self._chk(self._lib.pose_amd_best_mask(self._h, _ptr(m, _lib._u8)), "best_mask")

@@ -4,6 +4,9 @@
 #include "../../include/pose_amd.h"
 #include "kernels.h"
 #include <algorithm>
+#include <atomic>
+#include <mutex>
+#include <thread>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -37,6 +40,8 @@ struct pose_amd_ctx {
     float xmax = 0, umax = 0;      // largest |coordinate| and largest |centred keypoint coordinate| of the query
     bool score_fp64_only = false;  // POSE_AMD_SCORE=fp64: skip the float32 screen (for A/B checks)
     dev_buf projf;
+    // batch entry point: child contexts (one stream each) and their pinned result words
+    std::vector<pose_amd_ctx *> lanes;
     // hypotheses
     uint32_t hyp_count = 0;
     int solver = POSE_AMD_SOLVER_P4PF;
@@ -179,6 +184,7 @@ void pose_amd_destroy(pose_amd_ctx *c)
                        &c->maskw, &c->arows, &c->pstatus, &c->projf, &c->in0, &c->in1, &c->in2, &c->out0, &c->out1, &c->out2, &c->out3};
     for (dev_buf *b : bufs) if (b->p) (void)hipFree(b->p);
     for (int i = 0; i < 6; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+    for (pose_amd_ctx *l : c->lanes) pose_amd_destroy(l);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -668,6 +674,52 @@ int pose_amd_ransac_run(pose_amd_ctx *ctx, const pose_amd_params *prm, pose_amd_
         ctx->have_best = true;
     }
     return POSE_AMD_OK;
+}
+
+
+// ---- many queries -------------------------------------------------------------------------------
+// Queries are independent (benchmark.cpp:24-36 has no state across iterations).  A few worker
+// threads, each owning a child context (its own stream and buffers), take queries from a shared
+// counter and run the ordinary per-query sequence on them; while one worker waits for its
+// chunk, the launches of the others keep the device busy.
+int pose_amd_ransac_batch(pose_amd_ctx *ctx, int nq, const pose_amd_query *queries, int sample_mode, uint64_t seed,
+                          uint32_t budget, const pose_amd_params *prm, pose_amd_result *results)
+{
+    if (!ctx || nq < 0 || (nq && (!queries || !results)) || !prm) return fail(ctx, POSE_AMD_EINVAL, "ransac_batch: bad argument");
+    if (nq == 0) return POSE_AMD_OK;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    int nl = 8;
+    if (const char *e = getenv("POSE_AMD_BATCH_LANES")) nl = std::max(1, std::min(64, atoi(e)));
+    nl = std::min(nl, nq);
+    while ((int)ctx->lanes.size() < nl) {
+        pose_amd_ctx *l = nullptr;
+        if (pose_amd_create(ctx->device, &l) != POSE_AMD_OK) return fail(ctx, POSE_AMD_EHIP, "ransac_batch: cannot create an internal stream");
+        ctx->lanes.push_back(l);
+    }
+    std::atomic<int> next(0), status(POSE_AMD_OK);
+    std::mutex err_lock;
+    auto worker = [&](pose_amd_ctx *l) {
+        if (hipSetDevice(l->device) != hipSuccess) { status = POSE_AMD_EHIP; return; }
+        for (;;) {
+            const int i = next.fetch_add(1);
+            if (i >= nq || status.load() != POSE_AMD_OK) return;
+            const pose_amd_query &q = queries[i];
+            int rc = pose_amd_set_query(l, q.n, q.kx, q.ky, q.X, q.Y, q.Z, q.lindex, q.width, q.height, q.focal);
+            if (!rc && sample_mode == POSE_AMD_SAMPLE_ADVANCED) rc = pose_amd_set_camsets(l, q.cam_off, q.cam_ids);
+            if (!rc) rc = pose_amd_sample(l, sample_mode, seed, q.query_id, 0, budget, nullptr);
+            if (!rc) rc = pose_amd_ransac_run(l, prm, &results[i], nullptr, nullptr);
+            if (rc) {
+                std::lock_guard<std::mutex> g(err_lock);
+                if (status.load() == POSE_AMD_OK) { status = rc; ctx->err = "ransac_batch: query " + std::to_string(i) + ": " + l->err; }
+                return;
+            }
+        }
+    };
+    std::vector<std::thread> pool;
+    for (int t = 1; t < nl; ++t) pool.emplace_back(worker, ctx->lanes[(size_t)t]);
+    worker(ctx->lanes[0]);
+    for (std::thread &t : pool) t.join();
+    return status.load();
 }
 
 int pose_amd_best_mask(pose_amd_ctx *ctx, uint8_t *mask)

@@ -463,3 +463,45 @@ def test_ransac_large_query_config5_shape(ctx):
         res = ctx.ransac_run(SELECT_INLIERS, 0.5, early_exit=False)
         keys.append(shard.pack_key(res["inliers"], b + res["best_hyp"]))
     assert shard.unpack_key(max(keys)) == (whole["inliers"], whole["best_hyp"])
+
+
+# ---- many queries in one call -------------------------------------------------------------------
+@pytest.mark.parametrize("select,early_exit", [(SELECT_INLIERS, True), (SELECT_INLIERS, False), (SELECT_COVERAGE, True)])
+def test_ransac_batch_equals_per_query_calls(ctx, select, early_exit):
+    """The pipelined multi-query entry point against one set_query + sample + ransac_run per
+    query: identical results (mixed known / unknown focal length, sizes, inlier ratios; one
+    query too small for the loop to start)."""
+    queries = []
+    for i, (n, frac, known) in enumerate([(900, 0.3, False), (700, 0.5, True), (1500, 0.12, False), (64, 0.9, True),
+                                          (9, 1.0, False), (1200, 0.2, True), (800, 0.35, False), (500, 0.4, True),
+                                          (1100, 0.15, False), (300, 0.6, False), (650, 0.25, True)]):
+        q = synth.make_query(n, frac, 100 + i, known_focal=known)
+        q["query_id"] = 40 + i
+        queries.append(q)
+    budget = 600
+    got = ctx.ransac_batch(queries, SAMPLE_BASIC, seed=77, budget=budget, select_mode=select, early_exit=early_exit)
+    assert len(got) == len(queries)
+    for q, g in zip(queries, got):
+        upload(ctx, q)
+        ctx.sample(SAMPLE_BASIC, 77, q["query_id"], 0, budget, export=False)
+        r = ctx.ransac_run(select, 0.5, early_exit)
+        for k in ("found", "inliers", "steps", "best_hyp", "best_sol", "poses_scored", "area_fit", "area_all"):
+            assert g[k] == r[k], (k, g[k], r[k], len(q["kx"]))
+        if r["found"]:
+            assert np.array_equal(g["C"], r["C"]) and np.array_equal(g["Rc"], r["Rc"]) and g["focal"] == r["focal"]
+
+
+def test_ransac_batch_advanced_and_empty(ctx):
+    assert ctx.ransac_batch([], SAMPLE_BASIC, seed=1, budget=10) == []
+    queries = []
+    for i in range(5):
+        q = synth.make_query(400 + 50 * i, 0.4, 200 + i, known_focal=bool(i & 1))
+        synth.add_camsets(q, seed=300 + i)
+        queries.append(q)
+    got = ctx.ransac_batch(queries, SAMPLE_ADVANCED, seed=5, budget=100, select_mode=SELECT_INLIERS, early_exit=False)
+    for i, (q, g) in enumerate(zip(queries, got)):
+        upload(ctx, q)
+        ctx.set_camsets(q["cam_off"], q["cam_ids"])
+        ctx.sample(SAMPLE_ADVANCED, 5, i, 0, 100, export=False)
+        r = ctx.ransac_run(SELECT_INLIERS, 0.5, False)
+        assert (g["found"], g["inliers"], g["steps"], g["best_hyp"]) == (r["found"], r["inliers"], r["steps"], r["best_hyp"])
