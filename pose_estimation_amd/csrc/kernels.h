@@ -570,7 +570,7 @@ __device__ __forceinline__ void load_posef_uniform(const float *__restrict__ pro
 }
 
 template <bool MASK>
-__global__ __launch_bounds__(SCORE_THREADS) void k_score_screen(query_dev q, int nslots, const double *__restrict__ proj,
+__global__ __launch_bounds__(SCORE_THREADS) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_score_screen(query_dev q, int nslots, const double *__restrict__ proj,
                                                                 const float *__restrict__ projf, const int *__restrict__ nsol,
                                                                 int maxsol, double eps, int *__restrict__ counts,
                                                                 unsigned long long *__restrict__ mask, int words_per_pose, int spb)
