@@ -79,6 +79,26 @@ __global__ void k(int iters, int src, double *out, long long *cyc)
                 a0 = fma(a0, sc, a4); a1 = fma(a1, sc, a5); a2 = fma(a2, sc, a6); a3 = fma(a3, sc, a0);
                 a4 = fma(a4, sc, a0); a5 = fma(a5, sc, a1); a6 = fma(a6, sc, a2); a3 = fma(a3, sc, a1);
             }
+        } else if (MODE == 9) {   // 16 LDS writes by one lane of each half
+            if ((lane & 31) == ((src + i) & 31)) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { my[j] = a0 + j; }
+                asm volatile("" ::: "memory");
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { my[j] = a1 + j; }
+            }
+            asm volatile("" ::: "memory");
+            a0 += 1.0;
+        } else if (MODE == 10) {  // 16 LDS broadcast reads (all lanes of a half read the same address)
+            double e[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) e[j] = my[j];
+            asm volatile("" ::: "memory");
+            a0 += e[0] + e[1] + e[2] + e[3]; a1 += e[4] + e[5] + e[6] + e[7];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) e[j] = my[(j + i) & 7];
+            asm volatile("" ::: "memory");
+            a2 += e[0] + e[1] + e[2] + e[3]; a3 += e[4] + e[5] + e[6] + e[7];
         } else if (MODE == 5) {   // LDS-staged: pivot lane of each half writes 8 doubles, all lanes read them (b64)
             if ((lane & 31) == ((src + i) & 31)) {
                 my[0] = a0; my[1] = a1; my[2] = a2; my[3] = a3; my[4] = a4; my[5] = a5; my[6] = a6; my[7] = a7;
@@ -146,6 +166,8 @@ int main()
         run<4>("dpp x16 + fma x8", w, 24);
         run<7>("readlane x16 only", w, 16);
         run<8>("fma x24 sgpr operand", w, 24);
+        run<9>("lds write x16 (2 lanes)", w, 16);
+        run<10>("lds bcast read x16 + add x16", w, 32);
         run<5>("lds b64 w8+r8 + fma x8", w, 24);
         run<6>("lds b128 w4+r4 + fma x8", w, 16);
     }
