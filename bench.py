@@ -29,6 +29,7 @@ HBM_PEAK_GBS = 8000.0
 # Algorithmic fp64 work per unit of each kernel (derivations in DESIGN.md):
 SCORE_FLOP_PER_PAIR = 27           # reference formula per (pose, correspondence): 3x4 product, 2 div, distance, compare
 ELIM_FLOP_PER_HYP = 2.28e4         # sparsity-exploiting elimination of the 78x88 template down to the 5x15 tail (22 285) + coefficient formulas
+P3P_FLOP_PER_HYP = 5.0e2           # Kneip P3P + Ferrari quartic per sample
 FINISH_FLOP_PER_HYP = 3.6e4        # executed fp64 lane-operations per hypothesis, from SQ_INSTS_VALU_*_F64 (profiles/r1_traffic.json)
 
 
@@ -42,6 +43,7 @@ def main():
     ap.add_argument("--inlier-frac", type=float, default=0.10)
     ap.add_argument("--cpu-hyps", type=int, default=0, help="CPU baseline sample size (0 = auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--known-focal", action="store_true", help="single: P3P instead of P4Pf (BASELINE configs[0] shape with --matches 2000 --inlier-frac 0.3)")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="process-group backend; gloo (CPU tensors) lets several ranks rehearse on one GPU")
     ap.add_argument("--workload", choices=["single", "dubrovnik"], default="single",
@@ -78,8 +80,8 @@ def main():
 
     from pose_estimation_amd import Context, shard, synth, SELECT_INLIERS, SAMPLE_BASIC
     ctx = Context(dev_index)
-    q = synth.make_query(args.matches, args.inlier_frac, seed=2)
-    ctx.set_query(q["kx"], q["ky"], q["X"], q["Y"], q["Z"], q["width"], q["height"], 0.0)
+    q = synth.make_query(args.matches, args.inlier_frac, seed=2, known_focal=args.known_focal)
+    ctx.set_query(q["kx"], q["ky"], q["X"], q["Y"], q["Z"], q["width"], q["height"], q["focal"])
     H = args.hyps
 
     def step(i):
@@ -125,9 +127,10 @@ def main():
         # library on its own stream around each kernel, averaged over the launches of the timed steps.
         launches = max(int(tim["launches"]), 1)
         hyps_rank = H * args.steps
-        work = {"k_p4pf_elim": (tim["elim_ms"], hyps_rank * ELIM_FLOP_PER_HYP),
+        work = {"k_solve_p3p": (tim["solve_ms"], hyps_rank * P3P_FLOP_PER_HYP)} if args.known_focal else {}
+        work.update({"k_p4pf_elim": (tim["elim_ms"], hyps_rank * ELIM_FLOP_PER_HYP),
                 "k_p4pf_finish": (tim["finish_ms"], hyps_rank * FINISH_FLOP_PER_HYP),
-                "k_score_screen": (tim["score_ms"], poses * args.matches * SCORE_FLOP_PER_PAIR)}
+                "k_score_screen": (tim["score_ms"], poses * args.matches * SCORE_FLOP_PER_PAIR)})
         dom = max(work, key=lambda k: work[k][0])
         dom_ms, dom_flop = work[dom]
         tflops = dom_flop / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
@@ -137,11 +140,12 @@ def main():
                     "kernel_ms_per_step": {k: round(v / args.steps, 3) for k, v in tim.items() if k.endswith("_ms")},
                     "kernel_tflops": {k: round(f / (ms * 1e-3) / 1e12, 3) for k, (ms, f) in work.items() if ms > 0},
                     "poses_per_hypothesis": round(poses / hyps_rank, 3)}
-        out = {"metric": "RANSAC hypotheses/sec (P4Pf solve+score)", "value": round(total_hyps / dt, 1), "unit": "hypotheses/s",
+        out = {"metric": "RANSAC hypotheses/sec (%s solve+score)" % ("P3P" if args.known_focal else "P4Pf"), "value": round(total_hyps / dt, 1), "unit": "hypotheses/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-               "config": {"workload": "%sP4Pf RANSAC, single query, %d matches, %g%% inliers, %d hypotheses per GPU per step"
-                          % ("BASELINE configs[1]: " if (args.matches, args.inlier_frac) == (4000, 0.10) else
+               "config": {"workload": ("%s" + ("P3P" if args.known_focal else "P4Pf") + " RANSAC, single query, %d matches, %g%% inliers, %d hypotheses per GPU per step")
+                          % ("BASELINE configs[0] shape: " if (args.matches, args.known_focal) == (2000, True) else
+                             "BASELINE configs[1]: " if (args.matches, args.inlier_frac) == (4000, 0.10) else
                              "BASELINE configs[4] shape: " if args.matches == 100000 else "", args.matches, args.inlier_frac * 100, H),
                           "select": "inlier count", "parallelism": "hypothesis range sharded over %d GPU(s)" % world,
                           "device": info["name"], "best_inliers": int(last["inliers"])},
@@ -150,7 +154,7 @@ def main():
             # the same step with the host->device hand-over of the query inside the timed region
             t1 = time.perf_counter()
             for i in range(2):
-                ctx.set_query(q["kx"], q["ky"], q["X"], q["Y"], q["Z"], q["width"], q["height"], 0.0)
+                ctx.set_query(q["kx"], q["ky"], q["X"], q["Y"], q["Z"], q["width"], q["height"], q["focal"])
                 step(args.warmup + args.steps + i)
             ctx.synchronize()
             out["config"]["pcie_inclusive_hypotheses_per_s"] = round(2 * H / (time.perf_counter() - t1), 1)
@@ -304,7 +308,7 @@ def cpu_baseline(ctx, q, args):
     import oracle_lib as O
     from pose_estimation_amd import SAMPLE_BASIC
     cores = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16")), 16)
-    kw = (q["kx"], q["ky"], q["X"], q["Y"], q["Z"], q["width"], q["height"], 0.0)
+    kw = (q["kx"], q["ky"], q["X"], q["Y"], q["Z"], q["width"], q["height"], q["focal"])
     probe = ctx.sample(SAMPLE_BASIC, 1002, 0, 0, 4096)
     probe[:, 3] = np.where(probe[:, 3] == 0xFFFFFFFF, 0, probe[:, 3])
     t0 = time.perf_counter()
