@@ -687,21 +687,32 @@ __global__ __launch_bounds__(SCORE_THREADS) __attribute__((amdgpu_waves_per_eu(6
 // the set bits.  all_matches != 0 paints every correspondence (the match_area map).
 // ------------------------------------------------------------------------------------------
 // With `slots` the i-th pose is proj[slots[i]] (candidate poses picked out of a chunk).
-// gridDim.y blocks share one pose (bitmaps and areas are zeroed by the host beforehand):
-// k_coverage paints, k_coverage_count adds up the set bits.
+// The bitmap never leaves the chip: blockIdx.y selects a band of `band_rows` image rows whose
+// bitmap (band_rows x words_per_row words, dynamic LDS) is painted with LDS atomics and counted
+// in place; the band sums are added up in areas[pose] (zeroed by the host beforehand).
 __global__ __launch_bounds__(256) void k_coverage(query_dev q, int nposes, const double *__restrict__ proj, const int *__restrict__ slots,
-                                                  double eps, int all_matches, unsigned int *__restrict__ bitmaps, int words_per_row)
+                                                  double eps, int all_matches, int band_rows, int words_per_row,
+                                                  unsigned long long *__restrict__ areas)
 {
+    extern __shared__ unsigned int s_bm[];
+    __shared__ unsigned long long s_sum[256];
     const int pose = blockIdx.x;
     if (pose >= nposes) return;
     const int tid = threadIdx.x;
-    const size_t nwords = (size_t)words_per_row * q.height;
-    unsigned int *bm = bitmaps + (size_t)pose * nwords;
+    const int row0 = blockIdx.y * band_rows, row1 = min(q.height, row0 + band_rows);
+    const int nwords = (row1 - row0) * words_per_row;
+    for (int i = tid; i < nwords; i += blockDim.x) s_bm[i] = 0u;
+    __syncthreads();
     const double hw = (double)q.width / 2.0, hh = (double)q.height / 2.0;
     const double *P = proj + (size_t)(slots ? slots[pose] : pose) * 12;
     const int cover = (int)ceilf((float)q.width / 20.0f);
-    for (int i = blockIdx.y * blockDim.x + tid; i < q.n; i += gridDim.y * blockDim.x) {
-        bool in = true;
+    for (int i = tid; i < q.n; i += blockDim.x) {
+        const int x = (int)rintf(q.kx[i]), y = (int)rintf(q.ky[i]);
+        const int sx = max(0, min(x - cover / 2, q.width - 1)), sy = max(0, min(y - cover / 2, q.height - 1));
+        const int ex = max(0, min(x + cover / 2, q.width - 1)), ey = max(0, min(y + cover / 2, q.height - 1));
+        if (!(sy < ey && sx < ex)) continue;
+        const int r0 = max(sy, row0), r1 = min(ey, row1);
+        if (r0 >= r1) continue;                              // the box does not touch this band
         if (!all_matches) {
             const double X = q.X[i], Y = q.Y[i], Z = q.Z[i];
             const double u = -((double)q.kx[i] - hw), v = -((double)q.ky[i] - hh);
@@ -710,35 +721,21 @@ __global__ __launch_bounds__(256) void k_coverage(query_dev q, int nposes, const
             const double pz = fma(P[8], X, fma(P[9], Y, fma(P[10], Z, P[11])));
             const double rx = fma(u, pz, -px), ry = fma(v, pz, -py);
             const double te = eps * pz;
-            in = fma(ry, ry, rx * rx) < te * te;
+            if (!(fma(ry, ry, rx * rx) < te * te)) continue;
         }
-        if (!in) continue;
-        const int x = (int)rintf(q.kx[i]), y = (int)rintf(q.ky[i]);
-        const int sx = max(0, min(x - cover / 2, q.width - 1)), sy = max(0, min(y - cover / 2, q.height - 1));
-        const int ex = max(0, min(x + cover / 2, q.width - 1)), ey = max(0, min(y + cover / 2, q.height - 1));
-        if (!(sy < ey && sx < ex)) continue;
         const int w0 = sx >> 5, w1 = (ex - 1) >> 5;
-        for (int r = sy; r < ey; ++r) {
+        for (int r = r0; r < r1; ++r) {
             for (int w = w0; w <= w1; ++w) {
                 unsigned int bits = 0xFFFFFFFFu;
                 if (w == w0) bits &= 0xFFFFFFFFu << (sx & 31);
                 if (w == w1) bits &= 0xFFFFFFFFu >> (31 - ((ex - 1) & 31));
-                atomicOr(&bm[(size_t)r * words_per_row + w], bits);
+                atomicOr(&s_bm[(r - row0) * words_per_row + w], bits);
             }
         }
     }
-}
-
-__global__ __launch_bounds__(256) void k_coverage_count(int nposes, size_t nwords, const unsigned int *__restrict__ bitmaps,
-                                                        unsigned long long *__restrict__ areas)
-{
-    const int pose = blockIdx.x;
-    if (pose >= nposes) return;
-    const int tid = threadIdx.x;
-    const unsigned int *bm = bitmaps + (size_t)pose * nwords;
-    __shared__ unsigned long long s_sum[256];
+    __syncthreads();
     unsigned long long a = 0;
-    for (size_t i = (size_t)blockIdx.y * blockDim.x + tid; i < nwords; i += (size_t)gridDim.y * blockDim.x) a += __popc(bm[i]);
+    for (int i = tid; i < nwords; i += blockDim.x) a += __popc(s_bm[i]);
     s_sum[tid] = a;
     __syncthreads();
     for (int o = 128; o > 0; o >>= 1) { if (tid < o) s_sum[tid] += s_sum[tid + o]; __syncthreads(); }

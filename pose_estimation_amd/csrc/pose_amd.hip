@@ -403,22 +403,23 @@ static int coverage_dev(pose_amd_ctx *ctx, int nposes, const double *proj_dev, d
 {
     const query_dev q = make_query(ctx);
     const int wpr = (ctx->width + 31) / 32;
-    const size_t words = (size_t)wpr * ctx->height;
     int rc;
     if ((rc = ensure(ctx, ctx->areas, (size_t)nposes * 8))) return rc;
     HIPCHK(ctx, hipMemsetAsync(ctx->areas.p, 0, (size_t)nposes * 8, ctx->stream));
-    const int chunk_max = 256;
+    // Bands of image rows: at most what fits 48 KB of LDS (three blocks per compute unit); thinner
+    // when few poses are evaluated, so that about 2 000 blocks exist and a single pose (the
+    // all-matches map, a candidate with thousands of inliers) is not painted by a handful of them.
+    if ((size_t)wpr * 4 > 48 * 1024) return fail(ctx, POSE_AMD_EINVAL, "coverage: image wider than 393216 px");
+    const int max_rows = std::max(1, std::min(ctx->height, (48 * 1024) / (wpr * 4)));
+    const int chunk_max = 16384;
     for (int p0 = 0; p0 < nposes; p0 += chunk_max) {
         const int cn = nposes - p0 < chunk_max ? nposes - p0 : chunk_max;
-        // few poses: several blocks share one pose so that painting thousands of boxes (the
-        // all-matches map, a pose with many inliers) does not run on a single compute unit
-        const int split = cn >= 128 ? 1 : std::min(32, std::max(1, cdiv(ctx->n, 256)));
-        if ((rc = ensure(ctx, ctx->bitmaps, (size_t)cn * words * 4))) return rc;
-        HIPCHK(ctx, hipMemsetAsync(ctx->bitmaps.p, 0, (size_t)cn * words * 4, ctx->stream));
-        hipLaunchKernelGGL(k_coverage, dim3(cn, split), dim3(256), 0, ctx->stream, q, cn, slots_dev ? proj_dev : proj_dev + (size_t)p0 * 12,
-                           slots_dev ? slots_dev + p0 : nullptr, eps, all_matches, (unsigned int *)ctx->bitmaps.p, wpr);
-        hipLaunchKernelGGL(k_coverage_count, dim3(cn, split), dim3(256), 0, ctx->stream, cn, words, (const unsigned int *)ctx->bitmaps.p,
-                           (unsigned long long *)ctx->areas.p + p0);
+        const int want_bands = std::min(cdiv(ctx->height, 8), cdiv(2048, cn));
+        const int band_rows = std::max(1, std::min(max_rows, cdiv(ctx->height, std::max(1, want_bands))));
+        const int bands = cdiv(ctx->height, band_rows);
+        hipLaunchKernelGGL(k_coverage, dim3(cn, bands), dim3(256), (size_t)band_rows * wpr * 4, ctx->stream, q, cn,
+                           slots_dev ? proj_dev : proj_dev + (size_t)p0 * 12, slots_dev ? slots_dev + p0 : nullptr, eps, all_matches,
+                           band_rows, wpr, (unsigned long long *)ctx->areas.p + p0);
         HIPCHK(ctx, hipGetLastError());
     }
     if ((rc = download(ctx, areas_host, ctx->areas.p, (size_t)nposes * 8))) return rc;
