@@ -607,11 +607,14 @@ int pose_amd_ransac_run(pose_amd_ctx *ctx, const pose_amd_params *prm, pose_amd_
             if ((rc = download(ctx, h_nsol.data(), ctx->nsol.p, (size_t)hc * 4)) ||
                 (rc = download(ctx, h_counts.data(), ctx->counts.p, nslots * 4)) || (rc = pose_amd_synchronize(ctx)))
                 return rc;
-            const int BATCH = 256;
-            areas.resize(BATCH);
+            // candidates are evaluated speculatively in batches; the first batch is small (it
+            // usually raises the pruning bound a lot), later ones grow so that a chunk full of
+            // candidates does not cost one host round trip per 256 poses
+            int BATCH = 256;
             size_t s = 0;
             while (!done && s < nslots) {
                 cand.clear();
+                areas.resize((size_t)BATCH);
                 size_t scan = s;
                 while (scan < nslots && (int)cand.size() < BATCH) {
                     const uint32_t h = (uint32_t)(scan / maxsol), k = (uint32_t)(scan % maxsol);
@@ -635,6 +638,7 @@ int pose_amd_ransac_run(pose_amd_ctx *ctx, const pose_amd_params *prm, pose_amd_
                     }
                 }
                 s = scan;
+                BATCH = std::min(4096, BATCH * 4);
             }
         }
         HIPCHK(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
