@@ -552,7 +552,10 @@ int pose_amd_ransac_run(pose_amd_ctx *ctx, const pose_amd_params *prm, pose_amd_
     const int maxsol = ctx->solver == POSE_AMD_SOLVER_P4PF ? P4PF_MAXSOL : P3P_MAXSOL;
     // Hypotheses are evaluated speculatively in chunks; the selection below replays them in
     // order, so the outcome equals the reference's one-step-at-a-time loop.
-    const uint32_t chunk = std::min<uint32_t>(H, prm->early_exit ? 2048u : 524288u);
+    // With early exit the chunks start small and grow (1 024, 4 096, 16 384, ...): most queries end
+    // in the first one, and the ones that do not should not pay one host round trip per 1 024 steps.
+    const uint32_t chunk = std::min<uint32_t>(H, prm->early_exit ? 16384u : 524288u);
+    uint32_t next_chunk = prm->early_exit ? std::min<uint32_t>(chunk, 1024u) : chunk;
     const size_t cslots = (size_t)chunk * maxsol;
     int rc;
     if ((rc = ensure(ctx, ctx->proj, cslots * 96)) || (rc = ensure(ctx, ctx->pose, cslots * 104)) ||
@@ -581,9 +584,10 @@ int pose_amd_ransac_run(pose_amd_ctx *ctx, const pose_amd_params *prm, pose_amd_
     std::vector<int> h_nsol, h_counts, cand;
     std::vector<int64_t> areas;
 
-    for (uint32_t h0 = 0; h0 < H && !done; h0 += chunk) {
+    for (uint32_t h0 = 0, hc = 0; h0 < H && !done; h0 += hc) {
         if (prm->early_exit && best_count >= thresh_u) break;          // loop condition, basic.cpp:132-133
-        const uint32_t hc = std::min(chunk, H - h0);
+        hc = std::min(next_chunk, H - h0);
+        next_chunk = std::min(chunk, next_chunk * 4);
         const size_t nslots = (size_t)hc * maxsol;
         if ((rc = solve_and_score(ctx, h0, hc, maxsol, prm->eps))) return rc;
         long long chunk_best = -1;       // slot within the chunk that became the kept pose
