@@ -26,7 +26,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 FP64_VECTOR_PEAK_TFLOPS = 78.6     # MI355X fp64 vector peak: 256 CU x 4 SIMD x 16 FMA lanes/clk x 2 x 2.4 GHz
 HBM_PEAK_GBS = 8000.0
-# Algorithmic fp64 work per unit of each kernel (derivations in DESIGN.md):
+# Algorithmic fp64 work per unit of each kernel:
 SCORE_FLOP_PER_PAIR = 27           # reference formula per (pose, correspondence): 3x4 product, 2 div, distance, compare
 ELIM_FLOP_PER_HYP = 2.28e4         # sparsity-exploiting elimination of the 78x88 template down to the 5x15 tail (22 285) + coefficient formulas
 P3P_FLOP_PER_HYP = 5.0e2           # Kneip P3P + Ferrari quartic per sample
