@@ -320,9 +320,16 @@ def cpu_baseline(ctx, q, args):
     t0 = time.perf_counter()
     O.ransac_fixed_budget(*kw, samples, threads=cores)
     dt = time.perf_counter() - t0
+    # the reference's own shape of the loop: one step after the other on one core, coverage-quality selection
+    ns = min(len(samples), max(256, int(4.0 / max(per * cores, 1e-8))))
+    t1 = time.perf_counter()
+    O.ransac(*kw, samples[:ns], select_coverage=True, early_exit=False, max_steps=ns)
+    dts = time.perf_counter() - t1
     return {"value": round(count / dt, 1), "unit": "hypotheses/s", "cores": cores, "kind": "port",
             "sample": "first %d hypotheses of the same query and sample stream (tuples exported by the device sampler), "
-                      "oracle/pose_oracle.c with OpenMP over hypotheses, %.1f s" % (count, dt)}
+                      "oracle/pose_oracle.c with OpenMP over hypotheses, %.1f s" % (count, dt),
+            "serial_reference_loop": {"value": round(ns / dts, 1), "unit": "hypotheses/s", "cores": 1,
+                                      "sample": "first %d hypotheses, sequential loop with coverage-quality selection, %.1f s" % (ns, dts)}}
 
 
 if __name__ == "__main__":
