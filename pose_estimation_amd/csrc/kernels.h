@@ -656,8 +656,12 @@ __global__ __launch_bounds__(SCORE_THREADS) __attribute__((amdgpu_waves_per_eu(6
                             const int k = 2 * g + h;
                             if ((h ? n1 : n0) == 0) continue;
                             const bool ok = base + k * SCORE_THREADS + tid < q.n;
-                            const double ud = -((double)kx[k] - hw), vd = -((double)ky[k] - hh);
-                            const double Xd = (double)(h ? X[g].y : X[g].x), Yd = (double)(h ? Y[g].y : Y[g].x), Zd = (double)(h ? Z[g].y : Z[g].x);
+                            // the float64 operands are formed here, on demand: hoisted out of the pose loop
+                            // they would double the register footprint of the common path
+                            float kxf = kx[k], kyf = ky[k], xf = h ? X[g].y : X[g].x, yf = h ? Y[g].y : Y[g].x, zf = h ? Z[g].y : Z[g].x;
+                            asm volatile("" : "+v"(kxf), "+v"(kyf), "+v"(xf), "+v"(yf), "+v"(zf));
+                            const double ud = -((double)kxf - hw), vd = -((double)kyf - hh);
+                            const double Xd = (double)xf, Yd = (double)yf, Zd = (double)zf;
                             const double qx = fma(Pd[0], Xd, fma(Pd[1], Yd, fma(Pd[2], Zd, Pd[3])));
                             const double qy = fma(Pd[4], Xd, fma(Pd[5], Yd, fma(Pd[6], Zd, Pd[7])));
                             const double qz = fma(Pd[8], Xd, fma(Pd[9], Yd, fma(Pd[10], Zd, Pd[11])));
