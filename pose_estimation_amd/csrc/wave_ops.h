@@ -77,7 +77,7 @@ __device__ __forceinline__ int half_argmax_abs(double x, bool cand)
     m = max(m, (unsigned)__builtin_amdgcn_update_dpp(0, (int)m, 0x140, 0xf, 0xf, true));
     // combine the two rows of 16 lanes of each half: ds_swizzle bit mode, lane ^ 16
     m = max(m, (unsigned)__builtin_amdgcn_ds_swizzle((int)m, 0x401F));
-    const unsigned long long who = __ballot(key == m && cand);
+    const unsigned long long who = __builtin_amdgcn_ballot_w64(key == m && cand);
     const unsigned lo = (unsigned)who, hi = (unsigned)(who >> 32);
     const bool upper = (threadIdx.x & 32) != 0;
     const unsigned mine = upper ? hi : lo;
