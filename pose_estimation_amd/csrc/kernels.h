@@ -514,7 +514,8 @@ __global__ __launch_bounds__(SCORE_THREADS) void k_score(query_dev q, int nslots
 // "outside" only when the float32 value exceeds the threshold by more than a rigorous bound of
 // its own rounding error; every correspondence group in which some lane is not certified is
 // re-evaluated with the float64 test above, whose result alone decides.  Counts and masks are
-// therefore identical to k_score's.
+// therefore identical to k_score's.  Since D >= |rx|, the x residual alone is tested first and
+// the y row is computed only for the groups in which some pair passes.
 //
 // Bound.  eps32 = 2^-24.  With Sz >= sum_j |P2j||X~j| and Sxy likewise for rows 0 and 1 (from
 // the pose's row sums, the query's largest coordinate and its largest |u|, |v|):
@@ -639,15 +640,22 @@ __global__ __launch_bounds__(SCORE_THREADS) __attribute__((amdgpu_waves_per_eu(6
                 asm volatile("" : "+v"(tx), "+v"(ty), "+v"(tz));
 #pragma unroll
                 for (int g = 0; g < KC / 2; ++g) {
+                    // first the x residual alone: D >= |rx|, so rx^2 beyond the bound already certifies
+                    // "outside" and the y row is only needed for the few pairs that pass
                     const v2f px = pk_fma(P.p[0], X[g], pk_fma(P.p[1], Y[g], pk_fma(P.p[2], Z[g], tx)));
-                    const v2f py = pk_fma(P.p[4], X[g], pk_fma(P.p[5], Y[g], pk_fma(P.p[6], Z[g], ty)));
                     const v2f pz = pk_fma(P.p[8], X[g], pk_fma(P.p[9], Y[g], pk_fma(P.p[10], Z[g], tz)));
-                    const v2f rx = pk_fma(u[g], pz, -px), ry = pk_fma(v[g], pz, -py);
-                    const v2f d2 = pk_fma(ry, ry, rx * rx);
+                    const v2f rx = pk_fma(u[g], pz, -px);
+                    const v2f rx2 = rx * rx;
                     const v2f hi2 = pk_fma(pz * pz, KA, P.B);
-                    // lanes not certified outside, per correspondence of the pair
-                    const unsigned long long n0 = ~__ballot(d2.x > hi2.x);
-                    const unsigned long long n1 = ~__ballot(d2.y > hi2.y);
+                    unsigned long long n0 = ~__ballot(rx2.x > hi2.x);
+                    unsigned long long n1 = ~__ballot(rx2.y > hi2.y);
+                    if (n0 | n1) {
+                        const v2f py = pk_fma(P.p[4], X[g], pk_fma(P.p[5], Y[g], pk_fma(P.p[6], Z[g], ty)));
+                        const v2f ry = pk_fma(v[g], pz, -py);
+                        const v2f d2 = pk_fma(ry, ry, rx2);
+                        n0 = ~__ballot(d2.x > hi2.x);
+                        n1 = ~__ballot(d2.y > hi2.y);
+                    }
                     if (n0 | n1) {
                         double Pd[12];
                         load_pose_uniform(proj, slot, Pd);
