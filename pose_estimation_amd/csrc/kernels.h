@@ -638,15 +638,21 @@ __global__ __launch_bounds__(SCORE_THREADS) __attribute__((amdgpu_waves_per_eu(6
                 // most one scalar operand
                 v2f tx = P.p[3], ty = P.p[7], tz = P.p[11];
                 asm volatile("" : "+v"(tx), "+v"(ty), "+v"(tz));
+                // first the x residual alone, for all four groups (independent chains interleave):
+                // D >= |rx|, so rx^2 beyond the bound already certifies "outside" and the y row
+                // is only needed for the few pairs that pass
+                v2f pzg[KC / 2], rx2g[KC / 2], hi2g[KC / 2];
 #pragma unroll
                 for (int g = 0; g < KC / 2; ++g) {
-                    // first the x residual alone: D >= |rx|, so rx^2 beyond the bound already certifies
-                    // "outside" and the y row is only needed for the few pairs that pass
                     const v2f px = pk_fma(P.p[0], X[g], pk_fma(P.p[1], Y[g], pk_fma(P.p[2], Z[g], tx)));
-                    const v2f pz = pk_fma(P.p[8], X[g], pk_fma(P.p[9], Y[g], pk_fma(P.p[10], Z[g], tz)));
-                    const v2f rx = pk_fma(u[g], pz, -px);
-                    const v2f rx2 = rx * rx;
-                    const v2f hi2 = pk_fma(pz * pz, KA, P.B);
+                    pzg[g] = pk_fma(P.p[8], X[g], pk_fma(P.p[9], Y[g], pk_fma(P.p[10], Z[g], tz)));
+                    const v2f rx = pk_fma(u[g], pzg[g], -px);
+                    rx2g[g] = rx * rx;
+                    hi2g[g] = pk_fma(pzg[g] * pzg[g], KA, P.B);
+                }
+#pragma unroll
+                for (int g = 0; g < KC / 2; ++g) {
+                    const v2f pz = pzg[g], rx2 = rx2g[g], hi2 = hi2g[g];
                     unsigned long long n0 = ~__ballot(rx2.x > hi2.x);
                     unsigned long long n1 = ~__ballot(rx2.y > hi2.y);
                     if (n0 | n1) {
