@@ -172,16 +172,41 @@ __global__ __launch_bounds__(64 * SAMPLE_ADV_WAVES) void k_sample_advanced(query
     }
 }
 
+// Float32 copy of a projection matrix for the scoring screen: 32 floats, every entry twice
+// (operand pairs of the packed instructions), then the additive constant B of the screen's
+// error bound twice (derivation at k_score_screen).
+__device__ __forceinline__ void projf_from_proj(const double (&P)[12], double xmax, double umax, double eps, float *__restrict__ out32)
+{
+    const double e32 = 5.9604644775390625e-08, xm = xmax, um = umax;
+    double S[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) S[r] = (fabs(P[4 * r]) + fabs(P[4 * r + 1]) + fabs(P[4 * r + 2])) * xm + fabs(P[4 * r + 3]);
+    const double E = 1.01 * e32 * (5.02 * um * S[2] + 4.01 * fmax(S[0], S[1]));
+    const double c = 1.0001 * eps * 4.01 * e32 * S[2] + 1.4143 * E;
+    const double k1 = 1.0 + 2.0 * e32, kappa = 0.015625;
+    double B = c * c * (1.0 + k1 * k1 / kappa) * (1.0 + 9.5367431640625e-07);
+    float Bf = (float)B;
+    if ((double)Bf < B) Bf = __uint_as_float(__float_as_uint(Bf) + 1u);     // round up (B >= 0)
+    if (!(B == B) || !(B < 3.0e38)) Bf = __uint_as_float(0x7f800000u);      // never certifies
+    float4 *o = reinterpret_cast<float4 *>(out32);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) o[i] = make_float4((float)P[2 * i], (float)P[2 * i], (float)P[2 * i + 1], (float)P[2 * i + 1]);
+    o[6] = make_float4(Bf, Bf, 0.f, 0.f);
+    o[7] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
 // ------------------------------------------------------------------------------------------
 // Pose records.  Each hypothesis owns `maxsol` slots; slot s = hyp*maxsol + k.
 //   proj: 12 doubles (3x4 projection matrix fed to scoring)
 //   pose: 13 doubles (focal, C[3], Rc[9]) as QueryProcessor*::Process stores them
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ void store_pose(double *__restrict__ proj, double *__restrict__ pose, size_t slot, double f,
-                                           const double C[3], const double Rc[9])
+                                           const double C[3], const double Rc[9], float *__restrict__ projf, const query_dev &q,
+                                           double eps)
 {
     double P[12];
     compute_matrices(f, C, Rc, P);
+    if (projf) projf_from_proj(P, (double)q.xmax, (double)q.umax, eps, projf + slot * 32);
     double *pp = proj + slot * 12;
 #pragma unroll
     for (int i = 0; i < 12; ++i) pp[i] = P[i];
@@ -202,7 +227,7 @@ __device__ __forceinline__ void load_obs(const query_dev &q, uint32_t idx, doubl
 
 // P3P branch of the RANSAC step (query_processor_basic.cpp:228-291): one hypothesis per lane.
 __global__ void k_solve_p3p(query_dev q, uint32_t hyp_count, const uint32_t *__restrict__ samples, double *__restrict__ proj,
-                            double *__restrict__ pose, int *__restrict__ nsol)
+                            double *__restrict__ pose, int *__restrict__ nsol, float *__restrict__ projf, double eps)
 {
     const uint32_t h = blockIdx.x * blockDim.x + threadIdx.x;
     if (h >= hyp_count) return;
@@ -224,13 +249,14 @@ __global__ void k_solve_p3p(query_dev q, uint32_t hyp_count, const uint32_t *__r
     nsol[h] = st == 0 ? 4 : 0;
     if (st == 0) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) store_pose(proj, pose, (size_t)h * P3P_MAXSOL + k, q.focal, C[k], R[k]);
+        for (int k = 0; k < 4; ++k) store_pose(proj, pose, (size_t)h * P3P_MAXSOL + k, q.focal, C[k], R[k], projf, q, eps);
     }
 }
 
 // Converts a P4Pf solution (f, R, t) into the stored pose (basic.cpp:195-198): C = -R^T t, Rc = R^T.
 __device__ __forceinline__ void store_p4pf_solution(double *__restrict__ proj, double *__restrict__ pose, size_t slot, double f,
-                                                    const double R[9], const double t[3])
+                                                    const double R[9], const double t[3], float *__restrict__ projf, const query_dev &q,
+                                                    double eps)
 {
     double C[3], Rc[9];
 #pragma unroll
@@ -239,7 +265,7 @@ __device__ __forceinline__ void store_p4pf_solution(double *__restrict__ proj, d
 #pragma unroll
         for (int c = 0; c < 3; ++c) Rc[3 * r + c] = R[3 * c + r];
     }
-    store_pose(proj, pose, slot, f, C, Rc);
+    store_pose(proj, pose, slot, f, C, Rc, projf, q, eps);
 }
 
 __device__ __forceinline__ void gather_p4pf(const query_dev &q, const uint4 s, double m2d[8], double M3D[12])
@@ -329,7 +355,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_p4pf_finish(query_dev q, uint32_t hyp_count, const uint32_t *__restrict__ samples, const double *__restrict__ m2d_in,
                               const double *__restrict__ M3D_in, const double *__restrict__ Arows, const int *__restrict__ status,
                               double *__restrict__ proj, double *__restrict__ pose, int *__restrict__ nsol, double *__restrict__ fo,
-                              double *__restrict__ Ro, double *__restrict__ to)
+                              double *__restrict__ Ro, double *__restrict__ to, float *__restrict__ projf, double eps)
 {
     const size_t h = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (h >= hyp_count) return;
@@ -351,7 +377,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         double f, R[9], t[3];
         p4pf_pose_from_root(pb, roots[s], f, R, t);
         if (proj) {
-            store_p4pf_solution(proj, pose, h * P4PF_MAXSOL + s, f, R, t);
+            store_p4pf_solution(proj, pose, h * P4PF_MAXSOL + s, f, R, t, projf, q, eps);
         } else {
             fo[10 * h + s] = f;
             for (int r = 0; r < 9; ++r) Ro[90 * h + 9 * s + r] = R[r];
@@ -541,22 +567,7 @@ __global__ void k_make_projf(query_dev q, int nslots, const double *__restrict__
     double P[12];
 #pragma unroll
     for (int i = 0; i < 12; ++i) P[i] = proj[(size_t)slot * 12 + i];
-    const double e32 = 5.9604644775390625e-08, xm = (double)q.xmax, um = (double)q.umax;
-    double S[3];
-#pragma unroll
-    for (int r = 0; r < 3; ++r) S[r] = (fabs(P[4 * r]) + fabs(P[4 * r + 1]) + fabs(P[4 * r + 2])) * xm + fabs(P[4 * r + 3]);
-    const double E = 1.01 * e32 * (5.02 * um * S[2] + 4.01 * fmax(S[0], S[1]));
-    const double c = 1.0001 * eps * 4.01 * e32 * S[2] + 1.4143 * E;
-    const double k1 = 1.0 + 2.0 * e32, kappa = 0.015625;
-    double B = c * c * (1.0 + k1 * k1 / kappa) * (1.0 + 9.5367431640625e-07);
-    float Bf = (float)B;
-    if ((double)Bf < B) Bf = __uint_as_float(__float_as_uint(Bf) + 1u);     // round up (B >= 0)
-    if (!(B == B) || !(B < 3.0e38)) Bf = __uint_as_float(0x7f800000u);      // never certifies
-    float4 *o = reinterpret_cast<float4 *>(projf + (size_t)slot * 32);
-#pragma unroll
-    for (int i = 0; i < 6; ++i) o[i] = make_float4((float)P[2 * i], (float)P[2 * i], (float)P[2 * i + 1], (float)P[2 * i + 1]);
-    o[6] = make_float4(Bf, Bf, 0.f, 0.f);
-    o[7] = make_float4(0.f, 0.f, 0.f, 0.f);
+    projf_from_proj(P, (double)q.xmax, (double)q.umax, eps, projf + (size_t)slot * 32);
 }
 
 __device__ __forceinline__ v2f pk_fma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }

@@ -112,7 +112,7 @@ static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b)
 // P4Pf minimal solves for `count` hypotheses: cooperative elimination, then per-lane eigen
 // step and pose recovery.  Exactly one of (samples) / (m2d, M3D) is given.
 static int launch_p4pf(pose_amd_ctx *ctx, uint32_t count, const uint32_t *samples, const double *m2d, const double *M3D,
-                       double *proj, double *pose, int *nsol, double *fo, double *Ro, double *to)
+                       double *proj, double *pose, int *nsol, double *fo, double *Ro, double *to, float *projf = nullptr, double eps = 0.0)
 {
     int rc;
     if ((rc = ensure(ctx, ctx->arows, (size_t)count * P4PF_TAIL * 8)) || (rc = ensure(ctx, ctx->pstatus, (size_t)count * 4))) return rc;
@@ -128,7 +128,7 @@ static int launch_p4pf(pose_amd_ctx *ctx, uint32_t count, const uint32_t *sample
     HIPCHK(ctx, hipGetLastError());
     HIPCHK(ctx, hipEventRecord(ctx->ev[4], ctx->stream));     // end of the elimination kernel, for the per-kernel timing
     hipLaunchKernelGGL(k_p4pf_finish, dim3(cdiv(count, 64)), dim3(64), 0, ctx->stream, q, count, samples, m2d, M3D,
-                       (const double *)ctx->arows.p, (const int *)ctx->pstatus.p, proj, pose, nsol, fo, Ro, to);
+                       (const double *)ctx->arows.p, (const int *)ctx->pstatus.p, proj, pose, nsol, fo, Ro, to, projf, eps);
     HIPCHK(ctx, hipGetLastError());
     return POSE_AMD_OK;
 }
@@ -343,8 +343,9 @@ int pose_amd_compute_matrices_batch(pose_amd_ctx *ctx, int count, const double *
     return pose_amd_synchronize(ctx);
 }
 
+// projf_ready: the float32 pose copies of these slots were already written by the solver kernels
 static int launch_score(pose_amd_ctx *ctx, int nslots, const double *proj_dev, const int *nsol_dev, int maxsol, double eps,
-                        int *counts_dev, unsigned long long *mask_dev, int words_per_pose)
+                        int *counts_dev, unsigned long long *mask_dev, int words_per_pose, bool projf_ready = false)
 {
     const query_dev q = make_query(ctx);
     // slots per block: as many as possible (each block streams the correspondences once for all
@@ -353,10 +354,12 @@ static int launch_score(pose_amd_ctx *ctx, int nslots, const double *proj_dev, c
     while (spb > 8 && cdiv(nslots, spb) < (ctx->cus ? ctx->cus : 256) * 4) spb >>= 1;
     const dim3 grid(cdiv(nslots, spb)), block(SCORE_THREADS);
     if (!ctx->score_fp64_only) {
-        int rc;
-        if ((rc = ensure(ctx, ctx->projf, (size_t)nslots * 128))) return rc;
-        hipLaunchKernelGGL(k_make_projf, dim3(cdiv(nslots, 256)), dim3(256), 0, ctx->stream, q, nslots, proj_dev, nsol_dev, maxsol, eps,
-                           (float *)ctx->projf.p);
+        if (!projf_ready) {
+            int rc;
+            if ((rc = ensure(ctx, ctx->projf, (size_t)nslots * 128))) return rc;
+            hipLaunchKernelGGL(k_make_projf, dim3(cdiv(nslots, 256)), dim3(256), 0, ctx->stream, q, nslots, proj_dev, nsol_dev, maxsol, eps,
+                               (float *)ctx->projf.p);
+        }
         if (mask_dev)
             hipLaunchKernelGGL((k_score_screen<true>), grid, block, 0, ctx->stream, q, nslots, proj_dev, (const float *)ctx->projf.p,
                                nsol_dev, maxsol, eps, counts_dev, mask_dev, words_per_pose, spb);
@@ -516,19 +519,25 @@ static int solve_and_score(pose_amd_ctx *ctx, uint32_t h0, uint32_t hc, int maxs
     const query_dev q = make_query(ctx);
     const uint32_t *smp = (const uint32_t *)ctx->samples.p + (size_t)h0 * 4;
     int rc;
+    // the solver kernels also write the float32 pose copies the scoring screen reads
+    float *projf = nullptr;
+    if (!ctx->score_fp64_only) {
+        if ((rc = ensure(ctx, ctx->projf, (size_t)hc * maxsol * 128))) return rc;
+        projf = (float *)ctx->projf.p;
+    }
     HIPCHK(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
     if (ctx->solver == POSE_AMD_SOLVER_P4PF) {
         if ((rc = launch_p4pf(ctx, hc, smp, nullptr, nullptr, (double *)ctx->proj.p, (double *)ctx->pose.p, (int *)ctx->nsol.p,
-                              nullptr, nullptr, nullptr)))
+                              nullptr, nullptr, nullptr, projf, eps)))
             return rc;
     } else {
         hipLaunchKernelGGL(k_solve_p3p, dim3(cdiv(hc, 64)), dim3(64), 0, ctx->stream, q, hc, smp, (double *)ctx->proj.p,
-                           (double *)ctx->pose.p, (int *)ctx->nsol.p);
+                           (double *)ctx->pose.p, (int *)ctx->nsol.p, projf, eps);
     }
     HIPCHK(ctx, hipGetLastError());
     HIPCHK(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
     if ((rc = launch_score(ctx, (int)((size_t)hc * maxsol), (const double *)ctx->proj.p, (const int *)ctx->nsol.p, maxsol, eps,
-                           (int *)ctx->counts.p, nullptr, 0)))
+                           (int *)ctx->counts.p, nullptr, 0, projf != nullptr)))
         return rc;
     HIPCHK(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
     return POSE_AMD_OK;
