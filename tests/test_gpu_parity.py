@@ -524,3 +524,47 @@ def test_benchmark_driver_writes_reference_csv(ctx, tmp_path):
         f = [float(x) for x in l.split(",")]
         assert len(f) == 5 and abs(f[2] - r[2]) <= 1e-9 * max(1.0, abs(r[2]))
         assert r[2] < 3.0 and r[3] < 0.1 and abs(r[4]) < 0.05 * 1200
+
+
+def test_full_size_properties(ctx):
+    """BASELINE configs[1] at full size (4 000 matches, 2^20 hypotheses), where the oracle is too
+    slow to replay everything: properties that do not depend on the size.
+    (1) the screened scoring kernel and the float64-only kernel give identical per-pose counts;
+    (2) the kept pose is the first maximum of those counts; (3) two half ranges reduce to the
+    same winner as the whole range; (4) a sample of hypotheses agrees with the oracle."""
+    from pose_estimation_amd import Context, shard
+    n, H = 4000, 1 << 20
+    q = synth.make_query(n, 0.10, 2)
+    os.environ["POSE_AMD_SCORE"] = "fp64"
+    try:
+        ref_ctx = Context(0)
+    finally:
+        del os.environ["POSE_AMD_SCORE"]
+    with ref_ctx:
+        res = []
+        for c in (ctx, ref_ctx):
+            upload(c, q)
+            c.sample(SAMPLE_BASIC, 1002, 0, 0, H, export=False)
+            res.append(c.ransac_run(SELECT_INLIERS, 0.5, early_exit=False, hyp_count=H, want_per_hyp=True))
+    r, r64 = res
+    assert np.array_equal(r["nsol"], r64["nsol"]) and np.array_equal(r["counts"], r64["counts"])           # (1)
+    valid = np.arange(10)[None, :] < np.maximum(r["nsol"], 0)[:, None]
+    counts = np.where(valid, r["counts"], -1)
+    flat = int(np.argmax(counts))                                                                          # first maximum
+    assert (r["best_hyp"], r["best_sol"], r["inliers"]) == (flat // 10, flat % 10, counts.reshape(-1)[flat])  # (2)
+    assert r["steps"] == H and r["poses_scored"] == int(valid.sum())
+    keys = []
+    for k in range(2):                                                                                      # (3)
+        b, e = shard.hypothesis_shard(H, k, 2)
+        ctx.sample(SAMPLE_BASIC, 1002, 0, b, e - b, export=False)
+        part = ctx.ransac_run(SELECT_INLIERS, 0.5, early_exit=False)
+        keys.append(shard.pack_key(part["inliers"], b + part["best_hyp"]))
+    assert shard.unpack_key(max(keys)) == (r["inliers"], r["best_hyp"])
+    rng = np.random.default_rng(0)                                                                          # (4)
+    picks = np.concatenate([[r["best_hyp"]], rng.integers(0, H, 40)])
+    samples = ctx.sample(SAMPLE_BASIC, 1002, 0, 0, 4096)
+    for h in picks[picks < 4096][:20]:
+        o = O.ransac(q["kx"], q["ky"], q["X"], q["Y"], q["Z"], q["width"], q["height"], 0.0, samples[h:h + 1], select_coverage=False,
+                     early_exit=False, max_steps=1)
+        mine = counts[h].max() if valid[h].any() else 0
+        assert (o["hyposet"] if o["found"] else 0) == max(mine, 0)
