@@ -299,6 +299,63 @@ public:
         query.ComputeMatrices(dev_);
         return true;
     }
+
+    // The loop over queries of benchmark.cpp:24-36 in one call (pose_amd_ransac_batch): query i
+    // uses the random stream (seed, query_id + i).  Poses, focal lengths and projection matrices
+    // are written back into the queries like Process does; results[i] holds the loop statistics.
+    // fitted_matches are not produced here: TestHypothesis on the final pose returns them.
+    bool ProcessBatch(std::vector<Query *> &queries, std::vector<std::vector<SiftMatch> *> &good_matches,
+                      std::vector<feature_3D_info> &sifts, std::vector<pose_amd_result> &results)
+    {
+        const size_t nq = queries.size();
+        std::vector<std::vector<float>> store(nq * 5);
+        std::vector<std::vector<uint32_t>> lidx(nq);
+        std::vector<pose_amd_query> desc(nq);
+        for (size_t i = 0; i < nq; ++i) {
+            Query &q = *queries[i];
+            const std::vector<SiftMatch> &ms = *good_matches[i];
+            const size_t n = ms.size();
+            for (int a = 0; a < 5; ++a) store[5 * i + a].resize(n);
+            lidx[i].resize(n);
+            for (size_t k = 0; k < n; ++k) {
+                const SIFT_keypoint &kp = q.sift_keypoints()[ms[k].lindex];
+                const point3D &p = sifts[ms[k].mindex].point;
+                store[5 * i][k] = kp.x; store[5 * i + 1][k] = kp.y;
+                store[5 * i + 2][k] = p.x; store[5 * i + 3][k] = p.y; store[5 * i + 4][k] = p.z;
+                lidx[i][k] = ms[k].lindex;
+            }
+            pose_amd_query &d = desc[i];
+            std::memset(&d, 0, sizeof d);
+            d.n = (int)n;
+            d.kx = store[5 * i].data(); d.ky = store[5 * i + 1].data();
+            d.X = store[5 * i + 2].data(); d.Y = store[5 * i + 3].data(); d.Z = store[5 * i + 4].data();
+            d.lindex = lidx[i].data();
+            d.width = q.image_width(); d.height = q.image_height(); d.focal = q.focal_length();
+            d.query_id = query_id + (uint32_t)i;
+        }
+        pose_amd_params prm;
+        std::memset(&prm, 0, sizeof prm);
+        prm.select_mode = select_mode; prm.eps = inlier_eps; prm.early_exit = 1;
+        prm.inlier_divisor = inlier_divisor; prm.inlier_absolute = inlier_absolute;
+        results.assign(nq, pose_amd_result{});
+        dev_->check(pose_amd_ransac_batch(dev_->ctx(), (int)nq, desc.data(), POSE_AMD_SAMPLE_BASIC, seed, max_ransac_steps, &prm,
+                                          results.data()),
+                    "ransac_batch");
+        for (size_t i = 0; i < nq; ++i) {
+            const pose_amd_result &r = results[i];
+            Query &q = *queries[i];
+            if (r.found) {
+                if (q.focal_length() == 0.0) q.set_focal_length(r.focal);
+                q.set_camera_position(Vector3d(r.C));
+                Matrix3d Rc;
+                for (int a = 0; a < 3; ++a)
+                    for (int b = 0; b < 3; ++b) Rc(a, b) = r.Rc[3 * a + b];
+                q.set_camera_rotation(Rc);
+            }
+            q.ComputeMatrices(dev_);
+        }
+        return true;
+    }
 };
 
 class QueryProcessorAdvanced : public QueryProcessor {

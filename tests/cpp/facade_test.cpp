@@ -150,12 +150,46 @@ static void test_processors()
     }
 }
 
+// ProcessBatch must give every query the pose Process gives it with the same stream
+static void test_batch()
+{
+    std::vector<Scene> scenes;
+    for (int i = 0; i < 6; ++i) scenes.push_back(make_scene(500 + 40 * i, 150 + 20 * i, (i & 1) != 0, 20u + i));
+    std::vector<feature_3D_info> sifts;                 // one shared 3D point list, as in the reference
+    std::vector<Query *> queries;
+    std::vector<std::vector<SiftMatch> *> matches;
+    for (Scene &s : scenes) {
+        const unsigned base = (unsigned)sifts.size();
+        sifts.insert(sifts.end(), s.sifts.begin(), s.sifts.end());
+        for (SiftMatch &m : s.matches) m.mindex += base;
+        queries.push_back(&s.query);
+        matches.push_back(&s.matches);
+    }
+    QueryProcessorBasic basic;
+    basic.seed = 77; basic.query_id = 5;
+    std::vector<pose_amd_result> results;
+    CHECK(basic.ProcessBatch(queries, matches, sifts, results));
+    CHECK(results.size() == scenes.size());
+    for (size_t i = 0; i < scenes.size(); ++i) {
+        Scene single = make_scene(500 + 40 * (int)i, 150 + 20 * (int)i, (i & 1) != 0, 20u + (unsigned)i);
+        QueryProcessorBasic one;
+        one.seed = 77; one.query_id = 5 + (uint32_t)i;
+        CHECK(one.Process(single.query, single.matches, single.sifts));
+        CHECK(results[i].found == one.result.found && results[i].steps == one.result.steps && results[i].inliers == one.result.inliers);
+        CHECK(results[i].best_hyp == one.result.best_hyp);
+        const Vector3d a = scenes[i].query.camera_position(), b = single.query.camera_position();
+        CHECK(a(0, 0) == b(0, 0) && a(1, 0) == b(1, 0) && a(2, 0) == b(2, 0));
+        CHECK(scenes[i].query.focal_length() == single.query.focal_length());
+    }
+}
+
 int main()
 {
     try {
         test_p3p();
         test_p4pf();
         test_processors();
+        test_batch();
     } catch (const std::exception &e) {
         std::printf("EXCEPTION %s\n", e.what());
         return 2;
