@@ -568,3 +568,18 @@ def test_full_size_properties(ctx):
                      early_exit=False, max_steps=1)
         mine = counts[h].max() if valid[h].any() else 0
         assert (o["hyposet"] if o["found"] else 0) == max(mine, 0)
+
+
+@pytest.mark.parametrize("select", [SELECT_COVERAGE, SELECT_INLIERS])
+@pytest.mark.parametrize("known_focal,n,frac,steps", [(True, 700, 0.06, 8000), (False, 500, 0.12, 4000)])
+def test_ransac_early_exit_across_chunks(ctx, select, known_focal, n, frac, steps):
+    """Low inlier ratios: the early exit comes (if at all) after several speculative chunks of
+    growing size, and the outcome must still be that of the one-step-at-a-time loop."""
+    q = synth.make_query(n, frac, 77, known_focal=known_focal)
+    upload(ctx, q)
+    samples = ctx.sample(SAMPLE_BASIC, 4242, 0, 0, steps)
+    s = samples.copy()
+    s[:, 3] = np.where(s[:, 3] == 0xFFFFFFFF, 0, s[:, 3])
+    r, o = run_both(ctx, q, s, select, True, steps)
+    assert o["steps"] > 1024                      # the first chunk did not end it
+    assert_same_outcome(ctx, q, r, o, select)
