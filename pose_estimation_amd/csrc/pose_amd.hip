@@ -563,7 +563,7 @@ int pose_amd_ransac_run(pose_amd_ctx *ctx, const pose_amd_params *prm, pose_amd_
     // order, so the outcome equals the reference's one-step-at-a-time loop.
     // With early exit the chunks start small and grow (1 024, 4 096, 16 384, ...): most queries end
     // in the first one, and the ones that do not should not pay one host round trip per 1 024 steps.
-    const uint32_t chunk = std::min<uint32_t>(H, prm->early_exit ? 16384u : 524288u);
+    const uint32_t chunk = std::min<uint32_t>(H, prm->early_exit ? 16384u : 1048576u);
     uint32_t next_chunk = prm->early_exit ? std::min<uint32_t>(chunk, 1024u) : chunk;
     const size_t cslots = (size_t)chunk * maxsol;
     int rc;
