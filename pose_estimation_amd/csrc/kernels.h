@@ -349,6 +349,53 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     }
 }
 
+// The same with four systems per pass (p4pf_elim_quad); `batch` is a multiple of 4.
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_p4pf_elim_quad(query_dev q, uint32_t hyp_count, const uint32_t *__restrict__ samples,
+                                                  const double *__restrict__ m2d_in, const double *__restrict__ M3D_in,
+                                                  double *__restrict__ Arows, int *__restrict__ status, int batch)
+{
+    __shared__ double cf[ELIM_BATCH][43];
+    __shared__ int st_s[ELIM_BATCH];
+    __shared__ uint4 tab[32 * QUAD_TAB_VEC];
+    const int lane = threadIdx.x;
+    for (int i = lane; i < 32 * QUAD_TAB_VEC; i += 64) tab[i] = reinterpret_cast<const uint4 *>(c_elim_quad_tab)[i];
+    const uint32_t nbatch = (hyp_count + batch - 1) / batch;
+    for (uint32_t b = blockIdx.x; b < nbatch; b += gridDim.x) {
+        if (lane < batch) {
+            const size_t h = (size_t)b * batch + lane;
+            int st = -1;
+            double k[42];
+#pragma unroll
+            for (int g = 0; g < 42; ++g) k[g] = 0.0;
+            if (h < hyp_count) {
+                double m2d[8], M3D[12];
+                p4pf_fetch(q, samples, m2d_in, M3D_in, h, m2d, M3D);
+                p4pf_problem pb;
+                st = p4pf_normalise(m2d, M3D, pb);
+                if (st == 0)
+                    p4pf_coefs(pb.gl[0], pb.gl[1], pb.gl[2], pb.gl[3], pb.gl[4], pb.gl[5], pb.m2D[0], pb.m2D[1], pb.m2D[2], pb.m2D[3],
+                               pb.m2D[4], pb.m2D[5], pb.m2D[6], pb.m2D[7], k);
+            }
+#pragma unroll
+            for (int g = 0; g < 42; ++g) cf[lane][g] = k[g];
+            cf[lane][42] = 0.0;
+            st_s[lane] = st;
+        }
+        __syncthreads();
+        // four systems per pass: the row of 16 lanes r eliminates system 4i + r
+        for (int i = 0; i < batch / 4; ++i) {
+            const int sys = 4 * i + (lane >> 4);
+            const size_t h = (size_t)b * batch + sys;
+            if ((size_t)b * batch + 4 * i >= hyp_count) break;
+            const int st = st_s[sys];
+            const bool live = h < hyp_count;
+            const int rc = p4pf_elim_quad(&cf[sys][0], tab, Arows + (live ? h : 0), (size_t)hyp_count, live && st == 0);
+            if ((lane & 15) == 0 && live) status[h] = st != 0 ? -1 : rc;
+        }
+        __syncthreads();
+    }
+}
+
 // P4Pf, stage C: one hypothesis per lane.  Action matrix -> accepted roots -> (f, R, t).
 // With proj != null the solutions go to the pose slots of the RANSAC pipeline, otherwise to
 // the flat arrays of the batch entry point.

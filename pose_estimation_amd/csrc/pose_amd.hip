@@ -123,6 +123,13 @@ static int launch_p4pf(pose_amd_ctx *ctx, uint32_t count, const uint32_t *sample
     int batch = 2 * cdiv(cdiv(count, slots), 2);
     batch = std::max(2, std::min(batch, ELIM_BATCH));
     const int nbatch = cdiv(count, batch);
+    static const bool quad = getenv("POSE_AMD_ELIM_QUAD") != nullptr;
+    if (quad) {
+        int b4 = 4 * cdiv(cdiv(count, slots), 4);
+        b4 = std::max(4, std::min(b4, ELIM_BATCH));
+        hipLaunchKernelGGL(k_p4pf_elim_quad, dim3(std::min(cdiv(count, b4), slots)), dim3(64), 0, ctx->stream, q, count, samples, m2d, M3D,
+                           (double *)ctx->arows.p, (int *)ctx->pstatus.p, b4);
+    } else
     hipLaunchKernelGGL(k_p4pf_elim, dim3(std::min(nbatch, slots)), dim3(64), 0, ctx->stream, q, count, samples, m2d, M3D,
                        (double *)ctx->arows.p, (int *)ctx->pstatus.p, batch);
     HIPCHK(ctx, hipGetLastError());

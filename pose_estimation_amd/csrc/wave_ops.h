@@ -84,4 +84,28 @@ __device__ __forceinline__ int half_argmax_abs(double x, bool cand)
     return (upper ? 32 : 0) + (mine ? (int)__builtin_ctz(mine) : 0);
 }
 
+// ---- four independent rows of 16 lanes, two values per lane ---------------------------------
+
+// Every lane holds two candidates (x0: position lane % 16, x1: position 16 + lane % 16) of its
+// row's system.  Returns the absolute lane number of the candidate with the largest |x| inside
+// the caller's row of 16 lanes and sets `second` when it is that lane's x1 (float32 key; the
+// lowest position wins ties; the row's first lane, second = true, if there is no candidate).
+__device__ __forceinline__ int row16_argmax_abs(double x0, bool c0, double x1, bool c1, bool &second)
+{
+    const unsigned k0 = c0 ? (__float_as_uint((float)fabs(x0)) + 1u) : 0u;
+    const unsigned k1 = c1 ? (__float_as_uint((float)fabs(x1)) + 1u) : 0u;
+    unsigned m = max(k0, k1);
+    m = max(m, (unsigned)__builtin_amdgcn_update_dpp(0, (int)m, 0xB1, 0xf, 0xf, true));
+    m = max(m, (unsigned)__builtin_amdgcn_update_dpp(0, (int)m, 0x4E, 0xf, 0xf, true));
+    m = max(m, (unsigned)__builtin_amdgcn_update_dpp(0, (int)m, 0x141, 0xf, 0xf, true));
+    m = max(m, (unsigned)__builtin_amdgcn_update_dpp(0, (int)m, 0x140, 0xf, 0xf, true));
+    const unsigned long long w0 = __builtin_amdgcn_ballot_w64(k0 == m && c0);
+    const unsigned long long w1 = __builtin_amdgcn_ballot_w64(k1 == m && c1);
+    const int sh = (int)(threadIdx.x & 48);
+    const unsigned g0 = (unsigned)(w0 >> sh) & 0xffffu, g1 = (unsigned)(w1 >> sh) & 0xffffu;
+    second = g0 == 0;
+    const unsigned g = g0 ? g0 : g1;
+    return sh + (g ? (int)__builtin_ctz(g) : 0);
+}
+
 } // namespace pose_amd

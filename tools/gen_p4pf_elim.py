@@ -33,6 +33,7 @@ CONST = {0: 1.0, 2: -1.0, 3: -1.0, 12: 1.0, 14: -2.0, 22: 1.0, 24: -1.0, 32: 1.0
 LDS_SHARE = int(os.environ.get("P4PF_ELIM_LDS_SHARE", "5"))   # of every 8 pivot-row broadcasts, how many go through the LDS crossbar
 KEEP = list(range(70, 75))          # columns whose rows of Mr are needed
 RHS = list(range(78, 88))
+QUAD_CHUNK = int(os.environ.get("P4PF_ELIM_QUAD_CHUNK", "8"))   # pivot-row entries in flight per group of broadcasts (four-system layout)
 
 
 def load_template():
@@ -341,6 +342,132 @@ def emit(sched):
     return txt
 
 
+def emit_quad(sched):
+    """Four systems per wave: one per row of 16 lanes, two matrix rows per lane (row position
+    p = 16 * slot + lane % 16), one named register per (column, slot).  Every cross-lane
+    instruction then serves four systems instead of two.
+
+    Initial entries: register (column, slot) of a lane starts as coefficient id(position, column)
+    of its system (42 = structural zero).  The ids come from a byte table kept in LDS and laid out
+    [slot][position][order of first use], so that one 16-byte read gives a lane the ids of the
+    next 16 registers it initialises."""
+    o = []
+    w = o.append
+    order = [[], []]
+    w("// Same elimination with FOUR systems per wave (one per row of 16 lanes, two matrix rows per")
+    w("// lane).  cf points at the coefficients of this lane's system, tail5x15 at its output column,")
+    w("// tab at the LDS copy of c_elim_quad_tab.")
+    w("__device__ __forceinline__ int p4pf_elim_quad(const double *cf, const uint4 *tab, double *tail5x15, size_t stride, bool wr)")
+    w("{")
+    w("    const int lane = (int)(threadIdx.x & 63);")
+    w("    const int rl = lane & 15;")
+    w("    const int sh = lane & 48;")
+    w("    int bad = 0;")
+
+    def need(c, s):
+        if c in order[s]:
+            return
+        i = len(order[s])
+        order[s].append(c)
+        if i % 16 == 0:
+            w(f"    const uint4 t{s}_{i // 16} = tab[({16 * s} + rl) * QUAD_TAB_VEC + {i // 16}];")
+        comp = "xyzw"[(i % 16) // 4]
+        w(f"    double r{c}_{s} = cf[__builtin_amdgcn_ubfe(t{s}_{i // 16}.{comp}, {8 * (i % 4)}, 8)];")
+
+    for s in (0, 1):
+        kdone = set()
+
+        def kexpr(g):
+            if g in CONST:
+                return repr(CONST[g])
+            if g not in kdone:
+                kdone.add(g)
+                w(f"    const double k{g}_{s} = cf[{g}];")
+            return f"k{g}_{s}"
+
+        w(f"    // ---- stage 1, rows {16 * s}..{16 * s + 15}")
+        for si, st in enumerate(sched["steps"]):
+            pc, pv = st["col"], st["pv"]
+            need(pc, s)
+            for c2 in st["pattern"]:
+                need(c2, s)
+            ops = [(c2, kexpr(sched["orig"][st["row"]][c2])) for c2 in st["pattern"]]
+            w(f"    {{ // step {si}: column {pc}")
+            w(f"        const double m = r{pc}_{s} * {repr(-1.0 / pv)};")
+            for c2, ke in ops:
+                w(f"        r{c2}_{s} = fma(m, {ke}, r{c2}_{s});")
+            w("    }")
+        if s == 0:
+            w('    asm volatile("" ::: "memory");')
+    lane_of = sched["lane_of"]
+    surv = sorted(lane_of[r] for r in sched["survivors"])
+    m0 = sum(1 << L for L in surv if L < 16)
+    m1 = sum(1 << (L - 16) for L in surv if L >= 16)
+    w(f"    bool act0 = ((0x{m0:x}u >> rl) & 1u) != 0, act1 = ((0x{m1:x}u >> rl) & 1u) != 0;")
+    for si, st in enumerate(sched["stage2"]):
+        c = st["col"]
+        for s in (0, 1):
+            need(c, s)
+            for c2 in st["pattern"]:
+                need(c2, s)
+        w(f"    {{ // stage 2 step {si}: column {c}")
+        w("        bool sl;")
+        w(f"        const int L = row16_argmax_abs(r{c}_0, act0, r{c}_1, act1, sl);")
+        w(f"        const double pv = half_bcast(sl ? r{c}_1 : r{c}_0, L);")
+        w("        bad |= pv == 0.0;")
+        w("        const double nr = neg_rcp(pv);")
+        w("        const bool p0 = lane == L && !sl, p1 = lane == L && sl;")
+        w(f"        const double m0 = (act0 && !p0) ? r{c}_0 * nr : 0.0;")
+        w(f"        const double m1 = (act1 && !p1) ? r{c}_1 * nr : 0.0;")
+        pat = st["pattern"]
+        for i0 in range(0, len(pat), QUAD_CHUNK):
+            chunk = pat[i0:i0 + QUAD_CHUNK]
+            for c2 in chunk:
+                w(f"        const double e{c2} = half_bcast(sl ? r{c2}_1 : r{c2}_0, L);")
+            for c2 in chunk:
+                w(f"        r{c2}_0 = fma(m0, e{c2}, r{c2}_0);")
+                w(f"        r{c2}_1 = fma(m1, e{c2}, r{c2}_1);")
+        w("        act0 = act0 && !p0;")
+        w("        act1 = act1 && !p1;")
+        w("    }")
+    for c in KEEP + RHS:
+        need(c, 0)
+        need(c, 1)
+    w("    {")
+    w("        const unsigned a0 = (unsigned)(__ballot(act0) >> sh) & 0xffffu, a1 = (unsigned)(__ballot(act1) >> sh) & 0xffffu;")
+    w("        const int n0 = __popc(a0);")
+    w("        bad |= n0 + __popc(a1) != 5;")
+    w("        const unsigned below = (1u << rl) - 1u;")
+    w("        const int rank0 = __popc(a0 & below), rank1 = n0 + __popc(a1 & below);")
+    for s in (0, 1):
+        w(f"        if (wr && act{s} && rank{s} < 5) {{")
+        w(f"            double *o = tail5x15 + (size_t)(rank{s} * 15) * stride;")
+        for j, c in enumerate(KEEP + RHS):
+            w(f"            o[{j} * stride] = r{c}_{s};")
+        w("        }")
+    w("    }")
+    w("    return bad ? -1 : 0;")
+    w("}")
+    w("} // namespace pose_amd")
+    # the id table, in the order of first use found above
+    tbl = np.full((32, 88), 42, dtype=np.int64)
+    for r in sched["lanes_rows"]:
+        for c, g in sched["orig"][r].items():
+            tbl[lane_of[r], c] = g
+    nvec = (max(len(order[0]), len(order[1])) + 15) // 16
+    head = ["", "namespace pose_amd {",
+            f"constexpr int QUAD_TAB_VEC = {nvec};   // 16-byte vectors of coefficient ids per (slot, position)",
+            "// coefficient ids [slot * 16 + position][order of first use] of the initial matrix; 42 = structural zero",
+            f"__constant__ __attribute__((aligned(16))) unsigned char c_elim_quad_tab[32 * {nvec * 16}] = {{"]
+    for s in (0, 1):
+        for pos in range(16):
+            ids = [int(tbl[16 * s + pos, c]) for c in order[s]]
+            ids += [42] * (nvec * 16 - len(ids))
+            head.append("  " + ",".join(str(v) for v in ids) + ",")
+    head.append("};")
+    return "\n".join(head + o) + "\n"
+
+
 if __name__ == "__main__":
     s = build_schedule()
     n1 = len(s["steps"])
@@ -348,5 +475,5 @@ if __name__ == "__main__":
     print("stage 1 fma count:", sum(len(st["pattern"]) for st in s["steps"]))
     print("stage 2: %d columns, broadcast+fma count %d" % (len(s["stage2"]), sum(len(st["pattern"]) for st in s["stage2"])))
     out = os.path.join(ROOT, "pose_estimation_amd", "csrc", "p4pf_elim_gen.h")
-    open(out, "w").write(emit(s))
+    open(out, "w").write(emit(s) + emit_quad(s))
     print("wrote", out)
