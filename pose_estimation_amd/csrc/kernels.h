@@ -283,12 +283,12 @@ __device__ __forceinline__ void gather_p4pf(const query_dev &q, const uint4 s, d
 // P4Pf, stage A+B: template coefficients and the cooperative elimination.
 // One wave per block.  Phase A: lanes 0..31 each prepare one hypothesis (gather the four
 // correspondences, normalise, 42 coefficients -> LDS).  Phase B: the whole wave eliminates
-// the 32 systems two at a time (p4pf_elim_wave) and writes the reduced 5 x 15 tail system of
-// each (75 doubles, stored [75][hyp_count] so that the consumer reads it coalesced) plus a
-// status word.  Inputs come either from the resident query +
+// the 32 systems four at a time (p4pf_elim_wave: the row of 16 lanes r takes system 4i + r) and
+// writes the reduced 5 x 15 tail system of each (75 doubles, stored [75][hyp_count] so that the
+// consumer reads it coalesced) plus a status word.  Inputs come either from the resident query +
 // sample tuples or, for the batch entry point, from explicit m2d / M3D arrays.
 // ------------------------------------------------------------------------------------------
-constexpr int ELIM_BATCH = 32;     // systems per block and round at most; the launch passes an even `batch` <= this
+constexpr int ELIM_BATCH = 32;     // systems per block and round at most; the launch passes a `batch` <= this that is a multiple of 4
                                    // (small launches use small batches so that they still fill the chip)
 constexpr int P4PF_TAIL = 75;      // doubles per hypothesis between the elimination and the finish kernel, stored [75][count]
 
@@ -311,54 +311,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 {
     __shared__ double cf[ELIM_BATCH][43];
     __shared__ int st_s[ELIM_BATCH];
+    __shared__ uint4 tab[32 * ELIM_TAB_VEC];
+    __shared__ double2 pbuf[4][16];
     const int lane = threadIdx.x;
-    const uint32_t nbatch = (hyp_count + batch - 1) / batch;
-    for (uint32_t b = blockIdx.x; b < nbatch; b += gridDim.x) {
-        if (lane < batch) {
-            const size_t h = (size_t)b * batch + lane;
-            int st = -1;
-            double k[42];
-#pragma unroll
-            for (int g = 0; g < 42; ++g) k[g] = 0.0;
-            if (h < hyp_count) {
-                double m2d[8], M3D[12];
-                p4pf_fetch(q, samples, m2d_in, M3D_in, h, m2d, M3D);
-                p4pf_problem pb;
-                st = p4pf_normalise(m2d, M3D, pb);
-                if (st == 0)
-                    p4pf_coefs(pb.gl[0], pb.gl[1], pb.gl[2], pb.gl[3], pb.gl[4], pb.gl[5], pb.m2D[0], pb.m2D[1], pb.m2D[2], pb.m2D[3],
-                               pb.m2D[4], pb.m2D[5], pb.m2D[6], pb.m2D[7], k);
-            }
-#pragma unroll
-            for (int g = 0; g < 42; ++g) cf[lane][g] = k[g];
-            cf[lane][42] = 0.0;
-            st_s[lane] = st;
-        }
-        __syncthreads();
-        // two systems per pass: lanes 0..31 eliminate system 2i, lanes 32..63 system 2i+1
-        for (int i = 0; i < batch / 2; ++i) {
-            const int sys = 2 * i + (lane >> 5);
-            const size_t h = (size_t)b * batch + sys;
-            if ((size_t)b * batch + 2 * i >= hyp_count) break;
-            const int st = st_s[sys];
-            const bool live = h < hyp_count;
-            const int rc = p4pf_elim_wave(&cf[sys][0], Arows + (live ? h : 0), (size_t)hyp_count, live && st == 0);
-            if ((lane & 31) == 0 && live) status[h] = st != 0 ? -1 : rc;
-        }
-        __syncthreads();
-    }
-}
-
-// The same with four systems per pass (p4pf_elim_quad); `batch` is a multiple of 4.
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_p4pf_elim_quad(query_dev q, uint32_t hyp_count, const uint32_t *__restrict__ samples,
-                                                  const double *__restrict__ m2d_in, const double *__restrict__ M3D_in,
-                                                  double *__restrict__ Arows, int *__restrict__ status, int batch)
-{
-    __shared__ double cf[ELIM_BATCH][43];
-    __shared__ int st_s[ELIM_BATCH];
-    __shared__ uint4 tab[32 * QUAD_TAB_VEC];
-    const int lane = threadIdx.x;
-    for (int i = lane; i < 32 * QUAD_TAB_VEC; i += 64) tab[i] = reinterpret_cast<const uint4 *>(c_elim_quad_tab)[i];
+    for (int i = lane; i < 32 * ELIM_TAB_VEC; i += 64) tab[i] = reinterpret_cast<const uint4 *>(c_elim_tab)[i];
     const uint32_t nbatch = (hyp_count + batch - 1) / batch;
     for (uint32_t b = blockIdx.x; b < nbatch; b += gridDim.x) {
         if (lane < batch) {
@@ -389,7 +345,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             if ((size_t)b * batch + 4 * i >= hyp_count) break;
             const int st = st_s[sys];
             const bool live = h < hyp_count;
-            const int rc = p4pf_elim_quad(&cf[sys][0], tab, Arows + (live ? h : 0), (size_t)hyp_count, live && st == 0);
+            const int rc = p4pf_elim_wave(&cf[sys][0], tab, pbuf[lane >> 4], Arows + (live ? h : 0), (size_t)hyp_count, live && st == 0);
             if ((lane & 15) == 0 && live) status[h] = st != 0 ? -1 : rc;
         }
         __syncthreads();

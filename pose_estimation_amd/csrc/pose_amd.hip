@@ -118,19 +118,12 @@ static int launch_p4pf(pose_amd_ctx *ctx, uint32_t count, const uint32_t *sample
     if ((rc = ensure(ctx, ctx->arows, (size_t)count * P4PF_TAIL * 8)) || (rc = ensure(ctx, ctx->pstatus, (size_t)count * 4))) return rc;
     const query_dev q = make_query(ctx);
     // 32 systems per block amortise the coefficient phase; launches too small to give every
-    // wave slot of the chip a block that way use smaller (even) batches
+    // wave slot of the chip a block that way use smaller batches (multiples of 4: the systems
+    // one pass of the wave eliminates)
     const int slots = (ctx->cus ? ctx->cus : 256) * 8;
-    int batch = 2 * cdiv(cdiv(count, slots), 2);
-    batch = std::max(2, std::min(batch, ELIM_BATCH));
-    const int nbatch = cdiv(count, batch);
-    static const bool quad = getenv("POSE_AMD_ELIM_QUAD") != nullptr;
-    if (quad) {
-        int b4 = 4 * cdiv(cdiv(count, slots), 4);
-        b4 = std::max(4, std::min(b4, ELIM_BATCH));
-        hipLaunchKernelGGL(k_p4pf_elim_quad, dim3(std::min(cdiv(count, b4), slots)), dim3(64), 0, ctx->stream, q, count, samples, m2d, M3D,
-                           (double *)ctx->arows.p, (int *)ctx->pstatus.p, b4);
-    } else
-    hipLaunchKernelGGL(k_p4pf_elim, dim3(std::min(nbatch, slots)), dim3(64), 0, ctx->stream, q, count, samples, m2d, M3D,
+    int batch = 4 * cdiv(cdiv(count, slots), 4);
+    batch = std::max(4, std::min(batch, ELIM_BATCH));
+    hipLaunchKernelGGL(k_p4pf_elim, dim3(std::min(cdiv(count, batch), slots)), dim3(64), 0, ctx->stream, q, count, samples, m2d, M3D,
                        (double *)ctx->arows.p, (int *)ctx->pstatus.p, batch);
     HIPCHK(ctx, hipGetLastError());
     HIPCHK(ctx, hipEventRecord(ctx->ev[4], ctx->stream));     // end of the elimination kernel, for the per-kernel timing

@@ -4,16 +4,17 @@ elimination of the 78x88 P4Pf template (reference P4pf.cpp:959-1109).
 
 What the reference computes: Mr = M_left^-1 M_right (78x78 partial-pivot LU, 10 right-hand
 sides), of which only rows 70..74 feed the action matrix.  Equivalent elimination used here
-(TWO systems per 64-lane wave, one per 32-lane half; one matrix ROW per lane, columns = named
-registers):
+(FOUR systems per 64-lane wave, one per row of 16 lanes; TWO matrix rows per lane, row position
+p = 16 * slot + lane % 16; one named register per (column, slot)):
 
   stage 1  49 eliminations whose pivot is one of the template's constant entries (1, -1, -2).
            The order is chosen so that every pivot row is still in its original form when it
            is used: its entries are plain template coefficients, the same for all lanes of a
-           half, so no cross-lane traffic is needed and the pivot rows never occupy a lane.
-           Only the 29 rows that survive stage 1 are materialised (lanes 0..28 of each half).
+           system, so no cross-lane traffic is needed and the pivot rows never occupy a lane.
+           Only the 29 rows that survive stage 1 are materialised.
   stage 2  the remaining 24 columns, dynamic partial pivoting over the 29 surviving rows
-           (arg-max inside each half, pivot row broadcast with ds_bpermute).
+           (arg-max inside each row of 16 lanes with DPP; the pivot lane publishes its row
+           through LDS memory, everybody reads it back as a broadcast).
   tail     the 5 rows left over hold a 5 x 15 system in columns 70..74 | 78..87; it is written
            out and solved per lane by the consumer (p4pf_reduce_tail), where it costs no
            cross-lane traffic.
@@ -30,9 +31,9 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CONST = {0: 1.0, 2: -1.0, 3: -1.0, 12: 1.0, 14: -2.0, 22: 1.0, 24: -1.0, 32: 1.0, 34: -1.0}
-LDS_SHARE = int(os.environ.get("P4PF_ELIM_LDS_SHARE", "5"))   # of every 8 pivot-row broadcasts, how many go through the LDS crossbar
 KEEP = list(range(70, 75))          # columns whose rows of Mr are needed
 RHS = list(range(78, 88))
+QUAD_BCAST = os.environ.get("P4PF_ELIM_QUAD_BCAST", "lds_select")   # bpermute | lds_select | lds_branch
 QUAD_CHUNK = int(os.environ.get("P4PF_ELIM_QUAD_CHUNK", "8"))   # pivot-row entries in flight per group of broadcasts (four-system layout)
 
 
@@ -213,136 +214,6 @@ def simulate(sched, k):
 # HIP code generation
 # ---------------------------------------------------------------------------------------------
 def emit(sched):
-    o = []
-    w = o.append
-    lanes_rows, lane_of = sched["lanes_rows"], sched["lane_of"]
-    nl = len(lanes_rows)
-    w("// GENERATED by tools/gen_p4pf_elim.py -- do not edit.")
-    w("// Wave-cooperative elimination of the 78x88 P4Pf template: two systems per wave (one per")
-    w("// 32-lane half), one matrix row per lane, one named register per column.  See the generator")
-    w("// for the schedule.")
-    w("#pragma once")
-    w("namespace pose_amd {")
-    w(f"constexpr int P4PF_ELIM_LANES = {nl};   // lanes of each half that hold a matrix row")
-    # init table: for each lane of a half and column the coefficient id (42 = structural zero)
-    tbl = np.full((32, 88), 42, dtype=np.int64)
-    for r in lanes_rows:
-        for c, g in sched["orig"][r].items():
-            tbl[lane_of[r], c] = g
-    w("// coefficient id of entry (lane & 31, column) of the initial matrix; 42 = structural zero")
-    w("__constant__ unsigned char c_elim_init[88][32] = {")
-    for c in range(88):
-        w("  {" + ",".join(str(int(v)) for v in tbl[:, c]) + "},")
-    w("};")
-    w("")
-    w("// cf: LDS array of 43 doubles holding the 42 template coefficients of this lane's system and")
-    w("// 0.0 at index 42 (the pointer differs between the two halves of the wave).")
-    w("// Returns 0, or -1 when a pivot is exactly zero (same value in all lanes of a half).")
-    w("// tail5x15: the 5 rows that survive stage 2, columns 70..74 | 78..87; entry (r, j) goes to")
-    w("// tail5x15[(r * 15 + j) * stride], written by single lanes of each half when wr is set.")
-    w("__device__ __forceinline__ int p4pf_elim_wave(const double *cf, double *tail5x15, size_t stride, bool wr)")
-    w("{")
-    w("    const int lane = (int)(threadIdx.x & 63);")
-    w("    const int row = lane & 31;")
-    w("    const bool upper = lane >= 32;")
-    w("    int bad = 0;")
-    initialised = set()
-    kdone = set()
-
-    def need(c):
-        if c not in initialised:
-            initialised.add(c)
-            w(f"    double r{c} = cf[c_elim_init[{c}][row]];")
-
-    def kexpr(g):
-        if g in CONST:
-            return repr(CONST[g])
-        if g not in kdone:
-            kdone.add(g)
-            w(f"    const double k{g} = cf[{g}];")
-        return f"k{g}"
-
-    # Pivot-row broadcast, per 32-lane half.  Two routes share the work so that neither pipe is the
-    # bottleneck: the LDS crossbar (ds_bpermute, both halves in one instruction) and the vector
-    # ALU (v_readlane of each half's pivot lane into scalar registers, then a half-masked fma).
-    def bcast_fma(cols, chunk_size):
-        for i0 in range(0, len(cols), chunk_size):
-            chunk = cols[i0:i0 + chunk_size]
-            nl_ = (len(chunk) * LDS_SHARE + 7) // 8 if LDS_SHARE < 8 else len(chunk)
-            via_lds, via_alu = chunk[:nl_], chunk[nl_:]
-            for c2 in via_lds:
-                w(f"        const double e{c2} = half_bcast(r{c2}, L);")
-            for c2 in via_alu:
-                w(f"        const double a{c2} = wave_bcast(r{c2}, L0), b{c2} = wave_bcast(r{c2}, L1);")
-            for c2 in via_lds:
-                w(f"        r{c2} = fma(m, e{c2}, r{c2});")
-            if via_alu:
-                # two half-masked FMAs per column with the scalar operand read directly (the
-                # compiler would select between the halves with moves + v_cndmask instead)
-                lines = ['"s_mov_b32 exec_hi, 0\\n\\t"']
-                lines += [f'"v_fmac_f64 %[r{c2}], %[a{c2}], %[m]\\n\\t"' for c2 in via_alu]
-                lines += ['"s_mov_b32 exec_lo, 0\\n\\t"', '"s_mov_b32 exec_hi, -1\\n\\t"']
-                lines += [f'"v_fmac_f64 %[r{c2}], %[b{c2}], %[m]\\n\\t"' for c2 in via_alu]
-                lines += ['"s_mov_b32 exec_lo, -1"']
-                w("        asm volatile(" + "\n                     ".join(lines))
-                w("                     : " + ", ".join(f'[r{c2}] "+v"(r{c2})' for c2 in via_alu))
-                w("                     : [m] \"v\"(m), " + ", ".join(f'[a{c2}] "s"(a{c2}), [b{c2}] "s"(b{c2})' for c2 in via_alu) + ");")
-
-    # ---- stage 1
-    for si, st in enumerate(sched["steps"]):
-        pc, pv = st["col"], st["pv"]
-        need(pc)
-        for c2 in st["pattern"]:
-            need(c2)
-        ops = [(c2, kexpr(sched["orig"][st["row"]][c2])) for c2 in st["pattern"]]
-        w(f"    {{ // stage 1 step {si}: column {pc}, pivot row {st['row']} (original form)")
-        w(f"        const double m = r{pc} * {repr(-1.0 / pv)};")
-        for c2, ke in ops:
-            w(f"        r{c2} = fma(m, {ke}, r{c2});")
-        w("    }")
-    # ---- stage 2
-    surv_lanes = sorted(lane_of[r] for r in sched["survivors"])
-    mask = 0
-    for L in surv_lanes:
-        mask |= 1 << L
-    w(f"    bool active = ((0x{mask:x}u >> row) & 1u) != 0;   // the {len(surv_lanes)} surviving rows")
-    for si, st in enumerate(sched["stage2"]):
-        c = st["col"]
-        need(c)
-        for c2 in st["pattern"]:
-            need(c2)
-        w(f"    {{ // stage 2 step {si}: column {c}")
-        w(f"        const int L = half_argmax_abs(r{c}, active);")
-        w("        const int L0 = __builtin_amdgcn_readfirstlane(L), L1 = __builtin_amdgcn_readlane(L, 32);")
-        w(f"        const double pv = half_bcast(r{c}, L);")
-        w("        bad |= pv == 0.0;")
-        w(f"        const double m = (active && lane != L) ? r{c} * neg_rcp(pv) : 0.0;")
-        bcast_fma(st["pattern"], 8)
-        w("        active = active && lane != L;")
-        w("    }")
-    # ---- tail: the five rows still active hold the reduced 5 x 15 system (columns KEEP | RHS);
-    # its Gauss-Jordan solve needs no cross-lane traffic when done per lane by the consumer.
-    for c in KEEP + RHS:
-        need(c)
-    w("    {")
-    w("        const unsigned long long act = __ballot(active);")
-    w("        const unsigned mine = upper ? (unsigned)(act >> 32) : (unsigned)act;")
-    w("        bad |= __popc(mine) != 5;")
-    w("        const int rank = __popc(mine & ((1u << row) - 1u));")
-    w("        if (wr && active && rank < 5) {")
-    w("            double *o = tail5x15 + (size_t)(rank * 15) * stride;")
-    for j, c in enumerate(KEEP + RHS):
-        w(f"            o[{j} * stride] = r{c};")
-    w("        }")
-    w("    }")
-    w("    return bad ? -1 : 0;")
-    w("}")
-    w("} // namespace pose_amd")
-    txt = "\n".join(o) + "\n"
-    return txt
-
-
-def emit_quad(sched):
     """Four systems per wave: one per row of 16 lanes, two matrix rows per lane (row position
     p = 16 * slot + lane % 16), one named register per (column, slot).  Every cross-lane
     instruction then serves four systems instead of two.
@@ -354,15 +225,20 @@ def emit_quad(sched):
     o = []
     w = o.append
     order = [[], []]
-    w("// Same elimination with FOUR systems per wave (one per row of 16 lanes, two matrix rows per")
-    w("// lane).  cf points at the coefficients of this lane's system, tail5x15 at its output column,")
-    w("// tab at the LDS copy of c_elim_quad_tab.")
-    w("__device__ __forceinline__ int p4pf_elim_quad(const double *cf, const uint4 *tab, double *tail5x15, size_t stride, bool wr)")
+    w("// Wave-cooperative elimination of the 78x88 P4Pf template, FOUR systems per wave (one per row")
+    w("// of 16 lanes, two matrix rows per lane); see the generator for the schedule.")
+    w("// cf points at the 42 coefficients (+ 0.0 at index 42) of this lane's system in LDS, tail5x15")
+    w("// at its output column: entry (r, j) of the 5 x 15 tail system goes to tail5x15[(r * 15 + j)")
+    w("// * stride], written when wr is set.  Returns 0, or -1 when a pivot column had no usable entry.")
+    w("// tab at the LDS copy of c_elim_tab, pbuf at 16 double2 of LDS scratch private to the")
+    w("// lane's row of 16 lanes.")
+    w("__device__ __forceinline__ int p4pf_elim_wave(const double *cf, const uint4 *tab, double2 *pbuf, double *tail5x15, size_t stride, bool wr)")
     w("{")
     w("    const int lane = (int)(threadIdx.x & 63);")
     w("    const int rl = lane & 15;")
     w("    const int sh = lane & 48;")
     w("    int bad = 0;")
+    w("    const unsigned pbuf_addr = (unsigned)(size_t)pbuf;     // LDS byte address of the row's scratch")
 
     def need(c, s):
         if c in order[s]:
@@ -370,7 +246,7 @@ def emit_quad(sched):
         i = len(order[s])
         order[s].append(c)
         if i % 16 == 0:
-            w(f"    const uint4 t{s}_{i // 16} = tab[({16 * s} + rl) * QUAD_TAB_VEC + {i // 16}];")
+            w(f"    const uint4 t{s}_{i // 16} = tab[({16 * s} + rl) * ELIM_TAB_VEC + {i // 16}];")
         comp = "xyzw"[(i % 16) // 4]
         w(f"    double r{c}_{s} = cf[__builtin_amdgcn_ubfe(t{s}_{i // 16}.{comp}, {8 * (i % 4)}, 8)];")
 
@@ -411,24 +287,63 @@ def emit_quad(sched):
             for c2 in st["pattern"]:
                 need(c2, s)
         w(f"    {{ // stage 2 step {si}: column {c}")
-        w("        bool sl;")
-        w(f"        const int L = row16_argmax_abs(r{c}_0, act0, r{c}_1, act1, sl);")
-        w(f"        const double pv = half_bcast(sl ? r{c}_1 : r{c}_0, L);")
-        w("        bad |= pv == 0.0;")
+        w("        bool sl, none;")
+        w(f"        const int L = row16_argmax_abs(r{c}_0, act0, r{c}_1, act1, sl, none);")
+        w(f"        const double pv = lane_bcast(sl ? r{c}_1 : r{c}_0, L);")
+        w("        bad |= none;")
         w("        const double nr = neg_rcp(pv);")
-        w("        const bool p0 = lane == L && !sl, p1 = lane == L && sl;")
-        w(f"        const double m0 = (act0 && !p0) ? r{c}_0 * nr : 0.0;")
-        w(f"        const double m1 = (act1 && !p1) ? r{c}_1 * nr : 0.0;")
+        # rows that are retired (the pivot row included, from here on) are never read again, so
+        # their multipliers need no masking: whatever they accumulate stays in their own lane
+        w(f"        const double m0 = r{c}_0 * nr, m1 = r{c}_1 * nr;")
         pat = st["pattern"]
-        for i0 in range(0, len(pat), QUAD_CHUNK):
-            chunk = pat[i0:i0 + QUAD_CHUNK]
-            for c2 in chunk:
-                w(f"        const double e{c2} = half_bcast(sl ? r{c2}_1 : r{c2}_0, L);")
-            for c2 in chunk:
-                w(f"        r{c2}_0 = fma(m0, e{c2}, r{c2}_0);")
-                w(f"        r{c2}_1 = fma(m1, e{c2}, r{c2}_1);")
-        w("        act0 = act0 && !p0;")
-        w("        act1 = act1 && !p1;")
+        if QUAD_BCAST == "bpermute":
+            for i0 in range(0, len(pat), QUAD_CHUNK):
+                chunk = pat[i0:i0 + QUAD_CHUNK]
+                for c2 in chunk:
+                    w(f"        const double e{c2} = lane_bcast(sl ? r{c2}_1 : r{c2}_0, L);")
+                for c2 in chunk:
+                    w(f"        r{c2}_0 = fma(m0, e{c2}, r{c2}_0);")
+                    w(f"        r{c2}_1 = fma(m1, e{c2}, r{c2}_1);")
+        else:
+            # the pivot lane of each system publishes its row through LDS memory (16-byte writes by
+            # the four pivot lanes, 16-byte broadcast reads by everybody): half as many LDS
+            # instructions as ds_bpermute needs, and cheaper ones.  LDS instructions of one wave
+            # execute in order, so no wait is needed between the writes and the reads.
+            pairs = [pat[i:i + 2] for i in range(0, len(pat), 2)]
+            # exec-masked ds_write2_b64 in inline assembly: a divergent `if` would split the kernel's
+            # single basic block and wreck register allocation
+            def masked_writes(mask, name):
+                for g0 in range(0, len(pairs), 6):
+                    grp = pairs[g0:g0 + 6]
+                    lines = ['"s_mov_b64 exec, %[mask]\\n\\t"']
+                    for j, pr in enumerate(grp):
+                        lines.append(f'"ds_write2_b64 %[addr], %[a{j}], %[b{j}] offset0:{2 * (g0 + j)} offset1:{2 * (g0 + j) + 1}\\n\\t"')
+                    lines.append('"s_mov_b64 exec, -1"')
+                    w("        asm volatile(" + "\n                     ".join(lines))
+                    ops = ", ".join(f'[a{j}] "v"({name(pr[0])}), [b{j}] "v"({name(pr[-1])})' for j, pr in enumerate(grp))
+                    w(f'                     :: [mask] "s"({mask}), [addr] "v"(pbuf_addr), {ops} : "memory");')
+            if QUAD_BCAST == "lds_select":
+                for pr in pairs:
+                    for c2 in pr:
+                        w(f"        const double s{c2} = sl ? r{c2}_1 : r{c2}_0;")
+                w("        const unsigned long long wm = __builtin_amdgcn_ballot_w64(lane == L);")
+                masked_writes("wm", lambda c2: f"s{c2}")
+            else:
+                w("        const unsigned long long wm0 = __builtin_amdgcn_ballot_w64(lane == L && !sl), wm1 = __builtin_amdgcn_ballot_w64(lane == L && sl);")
+                masked_writes("wm0", lambda c2: f"r{c2}_0")
+                masked_writes("wm1", lambda c2: f"r{c2}_1")
+            w("        __builtin_amdgcn_wave_barrier();")
+            for i0 in range(0, len(pairs), QUAD_CHUNK // 2):
+                chunk = pairs[i0:i0 + QUAD_CHUNK // 2]
+                for j, pr in enumerate(chunk):
+                    w(f"        const double2 e{pr[0]} = pbuf[{i0 + j}];")
+                for pr in chunk:
+                    for c2, comp in zip(pr, "xy"):
+                        w(f"        r{c2}_0 = fma(m0, e{pr[0]}.{comp}, r{c2}_0);")
+                        w(f"        r{c2}_1 = fma(m1, e{pr[0]}.{comp}, r{c2}_1);")
+            w("        __builtin_amdgcn_wave_barrier();")
+        w("        act0 = act0 && !(lane == L && !sl);")
+        w("        act1 = act1 && !(lane == L && sl);")
         w("    }")
     for c in KEEP + RHS:
         need(c, 0)
@@ -455,10 +370,10 @@ def emit_quad(sched):
         for c, g in sched["orig"][r].items():
             tbl[lane_of[r], c] = g
     nvec = (max(len(order[0]), len(order[1])) + 15) // 16
-    head = ["", "namespace pose_amd {",
-            f"constexpr int QUAD_TAB_VEC = {nvec};   // 16-byte vectors of coefficient ids per (slot, position)",
+    head = ["// GENERATED by tools/gen_p4pf_elim.py -- do not edit.", "#pragma once", "namespace pose_amd {",
+            f"constexpr int ELIM_TAB_VEC = {nvec};   // 16-byte vectors of coefficient ids per (slot, position)",
             "// coefficient ids [slot * 16 + position][order of first use] of the initial matrix; 42 = structural zero",
-            f"__constant__ __attribute__((aligned(16))) unsigned char c_elim_quad_tab[32 * {nvec * 16}] = {{"]
+            f"__constant__ __attribute__((aligned(16))) unsigned char c_elim_tab[32 * {nvec * 16}] = {{"]
     for s in (0, 1):
         for pos in range(16):
             ids = [int(tbl[16 * s + pos, c]) for c in order[s]]
@@ -475,5 +390,5 @@ if __name__ == "__main__":
     print("stage 1 fma count:", sum(len(st["pattern"]) for st in s["steps"]))
     print("stage 2: %d columns, broadcast+fma count %d" % (len(s["stage2"]), sum(len(st["pattern"]) for st in s["stage2"])))
     out = os.path.join(ROOT, "pose_estimation_amd", "csrc", "p4pf_elim_gen.h")
-    open(out, "w").write(emit(s) + emit_quad(s))
+    open(out, "w").write(emit(s))
     print("wrote", out)
