@@ -4,6 +4,8 @@
 
 namespace pose_amd {
 
+typedef double v2f64 __attribute__((ext_vector_type(2)));   // two doubles in four consecutive VGPRs
+
 // -1/x to about one ulp: hardware reciprocal seed plus two Newton steps (cheaper than the
 // IEEE division sequence; used for elimination multipliers).
 __device__ __forceinline__ double neg_rcp(double x)

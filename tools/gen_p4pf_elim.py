@@ -33,8 +33,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CONST = {0: 1.0, 2: -1.0, 3: -1.0, 12: 1.0, 14: -2.0, 22: 1.0, 24: -1.0, 32: 1.0, 34: -1.0}
 KEEP = list(range(70, 75))          # columns whose rows of Mr are needed
 RHS = list(range(78, 88))
-QUAD_BCAST = os.environ.get("P4PF_ELIM_QUAD_BCAST", "lds_select")   # bpermute | lds_select | lds_branch
-QUAD_CHUNK = int(os.environ.get("P4PF_ELIM_QUAD_CHUNK", "8"))   # pivot-row entries in flight per group of broadcasts (four-system layout)
+QUAD_BCAST = os.environ.get("P4PF_ELIM_QUAD_BCAST", "lds")   # pivot-row broadcast: "lds" (write + broadcast read) or "bpermute"
+SKIP = os.environ.get("P4PF_ELIM_SKIP", "")    # timing experiments only: "stage1" or "stage2" leaves that stage out
+PREFETCH = int(os.environ.get("P4PF_ELIM_PREFETCH", "0"))     # stage-1 steps between an LDS read and its first use (0..8 measured the same)
+QUAD_CHUNK = int(os.environ.get("P4PF_ELIM_QUAD_CHUNK", "8"))   # pivot-row entries in flight per group of broadcasts
 
 
 def load_template():
@@ -245,28 +247,41 @@ def emit(sched):
             return
         i = len(order[s])
         order[s].append(c)
+        # id vectors are fetched one vector ahead of their first use
+        if i == 0:
+            w(f"    const uint4 t{s}_0 = tab[({16 * s} + rl) * ELIM_TAB_VEC];")
         if i % 16 == 0:
-            w(f"    const uint4 t{s}_{i // 16} = tab[({16 * s} + rl) * ELIM_TAB_VEC + {i // 16}];")
+            w(f"    [[maybe_unused]] const uint4 t{s}_{i // 16 + 1} = tab[({16 * s} + rl) * ELIM_TAB_VEC + {i // 16 + 1}];")
         comp = "xyzw"[(i % 16) // 4]
         w(f"    double r{c}_{s} = cf[__builtin_amdgcn_ubfe(t{s}_{i // 16}.{comp}, {8 * (i % 4)}, 8)];")
 
+    # Stage 1 is a chain of short dependent steps; its LDS reads (initial entries, pivot-row
+    # coefficients) can be issued PREFETCH steps ahead of the step that needs them.
+    steps = [] if SKIP in ("stage1", "both") else sched["steps"]
     for s in (0, 1):
         kdone = set()
 
-        def kexpr(g):
-            if g in CONST:
-                return repr(CONST[g])
-            if g not in kdone:
-                kdone.add(g)
-                w(f"    const double k{g}_{s} = cf[{g}];")
-            return f"k{g}_{s}"
-
-        w(f"    // ---- stage 1, rows {16 * s}..{16 * s + 15}")
-        for si, st in enumerate(sched["steps"]):
-            pc, pv = st["col"], st["pv"]
-            need(pc, s)
+        def fetch(st):
+            need(st["col"], s)
             for c2 in st["pattern"]:
                 need(c2, s)
+                g = sched["orig"][st["row"]][c2]
+                if g not in CONST and g not in kdone:
+                    kdone.add(g)
+                    w(f"    const double k{g}_{s} = cf[{g}];")
+
+        def kexpr(g):
+            return repr(CONST[g]) if g in CONST else f"k{g}_{s}"
+
+        w(f"    // ---- stage 1, rows {16 * s}..{16 * s + 15}")
+        if SKIP == "stage1b" and s == 1:
+            break
+        for st in steps[:PREFETCH]:
+            fetch(st)
+        for si, st in enumerate(steps):
+            if si + PREFETCH < len(steps):
+                fetch(steps[si + PREFETCH])
+            pc, pv = st["col"], st["pv"]
             ops = [(c2, kexpr(sched["orig"][st["row"]][c2])) for c2 in st["pattern"]]
             w(f"    {{ // step {si}: column {pc}")
             w(f"        const double m = r{pc}_{s} * {repr(-1.0 / pv)};")
@@ -281,6 +296,8 @@ def emit(sched):
     m1 = sum(1 << (L - 16) for L in surv if L >= 16)
     w(f"    bool act0 = ((0x{m0:x}u >> rl) & 1u) != 0, act1 = ((0x{m1:x}u >> rl) & 1u) != 0;")
     for si, st in enumerate(sched["stage2"]):
+        if SKIP in ("stage2", "both"):
+            break
         c = st["col"]
         for s in (0, 1):
             need(c, s)
@@ -317,21 +334,16 @@ def emit(sched):
                     grp = pairs[g0:g0 + 6]
                     lines = ['"s_mov_b64 exec, %[mask]\\n\\t"']
                     for j, pr in enumerate(grp):
-                        lines.append(f'"ds_write2_b64 %[addr], %[a{j}], %[b{j}] offset0:{2 * (g0 + j)} offset1:{2 * (g0 + j) + 1}\\n\\t"')
+                        lines.append(f'"ds_write_b128 %[addr], %[a{j}] offset:{16 * (g0 + j)}\\n\\t"')
                     lines.append('"s_mov_b64 exec, -1"')
                     w("        asm volatile(" + "\n                     ".join(lines))
-                    ops = ", ".join(f'[a{j}] "v"({name(pr[0])}), [b{j}] "v"({name(pr[-1])})' for j, pr in enumerate(grp))
+                    ops = ", ".join(f'[a{j}] "v"({name(pr)})' for j, pr in enumerate(grp))
                     w(f'                     :: [mask] "s"({mask}), [addr] "v"(pbuf_addr), {ops} : "memory");')
-            if QUAD_BCAST == "lds_select":
-                for pr in pairs:
-                    for c2 in pr:
-                        w(f"        const double s{c2} = sl ? r{c2}_1 : r{c2}_0;")
-                w("        const unsigned long long wm = __builtin_amdgcn_ballot_w64(lane == L);")
-                masked_writes("wm", lambda c2: f"s{c2}")
-            else:
-                w("        const unsigned long long wm0 = __builtin_amdgcn_ballot_w64(lane == L && !sl), wm1 = __builtin_amdgcn_ballot_w64(lane == L && sl);")
-                masked_writes("wm0", lambda c2: f"r{c2}_0")
-                masked_writes("wm1", lambda c2: f"r{c2}_1")
+            for pr in pairs:
+                a_, b_ = pr[0], pr[-1]
+                w(f"        const v2f64 s{a_} = {{sl ? r{a_}_1 : r{a_}_0, sl ? r{b_}_1 : r{b_}_0}};")
+            w("        const unsigned long long wm = __builtin_amdgcn_ballot_w64(lane == L);")
+            masked_writes("wm", lambda pr: f"s{pr[0]}")
             w("        __builtin_amdgcn_wave_barrier();")
             for i0 in range(0, len(pairs), QUAD_CHUNK // 2):
                 chunk = pairs[i0:i0 + QUAD_CHUNK // 2]
@@ -369,7 +381,7 @@ def emit(sched):
     for r in sched["lanes_rows"]:
         for c, g in sched["orig"][r].items():
             tbl[lane_of[r], c] = g
-    nvec = (max(len(order[0]), len(order[1])) + 15) // 16
+    nvec = (max(len(order[0]), len(order[1])) + 15) // 16 + 1     # + 1: the look-ahead fetch of the id vectors
     head = ["// GENERATED by tools/gen_p4pf_elim.py -- do not edit.", "#pragma once", "namespace pose_amd {",
             f"constexpr int ELIM_TAB_VEC = {nvec};   // 16-byte vectors of coefficient ids per (slot, position)",
             "// coefficient ids [slot * 16 + position][order of first use] of the initial matrix; 42 = structural zero",
