@@ -22,6 +22,26 @@ namespace pose_amd {
 
 #define PA_HD __host__ __device__ __forceinline__
 
+// 1/x.  On the device: hardware seed plus Newton steps instead of the IEEE division sequence
+// (`full`: two steps, about one ulp; otherwise one step, enough for iteration updates whose
+// result is re-checked anyway).  Exact division on the host.
+template <bool full = true>
+PA_HD double p4pf_rcp(double x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    double y = __builtin_amdgcn_rcp(x);
+    double e = fma(-x, y, 1.0);
+    y = fma(y, e, y);
+    if (full) {
+        e = fma(-x, y, 1.0);
+        y = fma(y, e, y);
+    }
+    return y;
+#else
+    return 1.0 / x;
+#endif
+}
+
 // out += s * a * b   (ascending coefficient arrays)
 template <int NA, int NB>
 PA_HD void poly_mac(double (&out)[NA + NB - 1], const double (&a)[NA], const double (&b)[NB], double s)
@@ -71,7 +91,7 @@ template <int N>
 PA_HD double poly_refine(const double (&c)[N + 1], double a, double b, double fa, double fb, double tol)
 {
     // start from the secant point of the bracket (both end values are known), kept away from the ends
-    double x = a - fa * (b - a) / (fb - fa);
+    double x = a - fa * (b - a) * p4pf_rcp<false>(fb - fa);
     const double margin = 0.05 * (b - a);
     x = fmin(fmax(x, a + margin), b - margin);
     for (int it = 0; it < P4PF_REFINE_ITS; ++it) {
@@ -79,7 +99,7 @@ PA_HD double poly_refine(const double (&c)[N + 1], double a, double b, double fa
         poly_eval2<N>(c, x, f, df);
         if (f == 0.0) return x;
         if ((f < 0.0) == (fa < 0.0)) a = x; else b = x;
-        double xn = x - f / df;
+        double xn = x - f * p4pf_rcp<false>(df);
         const bool newton = xn > a && xn < b;
         if (!newton) xn = 0.5 * (a + b);
         const double step = fabs(xn - x);
@@ -175,7 +195,7 @@ PA_HD void p4pf_build_system(const double (&a)[50], double L, double (&S)[5][5])
 // from the four pivot rows, y = (v2, v3, v4, v9).
 PA_HD double p4pf_solve_system(double (&S)[5][5], double (&y)[4])
 {
-    double det = 1.0;
+    double det = 1.0, ipv[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
 #pragma unroll
@@ -188,7 +208,8 @@ PA_HD double p4pf_solve_system(double (&S)[5][5], double (&y)[4])
         }
         const double pv = S[k][k];
         det *= pv;
-        const double ip = 1.0 / pv;
+        const double ip = p4pf_rcp(pv);
+        ipv[k] = ip;
 #pragma unroll
         for (int p = k + 1; p < 5; ++p) {
             const double m = S[p][k] * ip;
@@ -197,10 +218,10 @@ PA_HD double p4pf_solve_system(double (&S)[5][5], double (&y)[4])
         }
     }
     det *= S[4][4];
-    y[3] = S[3][4] / S[3][3];
-    y[2] = (S[2][4] - S[2][3] * y[3]) / S[2][2];
-    y[1] = (S[1][4] - S[1][2] * y[2] - S[1][3] * y[3]) / S[1][1];
-    y[0] = (S[0][4] - S[0][1] * y[1] - S[0][2] * y[2] - S[0][3] * y[3]) / S[0][0];
+    y[3] = S[3][4] * ipv[3];
+    y[2] = (S[2][4] - S[2][3] * y[3]) * ipv[2];
+    y[1] = (S[1][4] - S[1][2] * y[2] - S[1][3] * y[3]) * ipv[1];
+    y[0] = (S[0][4] - S[0][1] * y[1] - S[0][2] * y[2] - S[0][3] * y[3]) * ipv[0];
     return det;
 }
 
@@ -268,7 +289,7 @@ PA_HD int p4pf_reduce_tail(double (&t)[5][15], double (&a)[50])
         }
         const double pv = t[k][k];
         bad = bad || pv == 0.0;
-        const double ip = 1.0 / pv;
+        const double ip = p4pf_rcp(pv);
 #pragma unroll
         for (int j = k + 1; j < 15; ++j) t[k][j] *= ip;
 #pragma unroll
@@ -305,20 +326,21 @@ PA_HD int p4pf_roots_sextic(const double (&a)[50], const p4pf_problem &pb, p4pf_
     // the low-order ones from dividing bottom-up (each direction is accurate at its own end,
     // whatever the magnitude spread of the coefficients); they are joined where they agree best.
     double qt[7], qb[7], q[7];
-    qt[6] = p[10] / e2;
-    qt[5] = (p[9] - e1 * qt[6]) / e2;
+    const double ie2 = p4pf_rcp(e2), ie0 = p4pf_rcp(e0);
+    qt[6] = p[10] * ie2;
+    qt[5] = (p[9] - e1 * qt[6]) * ie2;
 #pragma unroll
-    for (int k = 4; k >= 0; --k) qt[k] = (p[k + 4] - e1 * qt[k + 1] - e0 * qt[k + 2]) / e2;
-    qb[0] = p[2] / e0;
-    qb[1] = (p[3] - e1 * qb[0]) / e0;
+    for (int k = 4; k >= 0; --k) qt[k] = (p[k + 4] - e1 * qt[k + 1] - e0 * qt[k + 2]) * ie2;
+    qb[0] = p[2] * ie0;
+    qb[1] = (p[3] - e1 * qb[0]) * ie0;
 #pragma unroll
-    for (int k = 2; k <= 6; ++k) qb[k] = (p[k + 2] - e1 * qb[k - 1] - e2 * qb[k - 2]) / e0;
+    for (int k = 2; k <= 6; ++k) qb[k] = (p[k + 2] - e1 * qb[k - 1] - e2 * qb[k - 2]) * ie0;
     int join = 0;
     double best = 1e300;
 #pragma unroll
     for (int k = 0; k < 7; ++k) {
         const double den = fabs(qt[k]) + fabs(qb[k]);
-        const double rel = den > 0.0 ? fabs(qt[k] - qb[k]) / den : 0.0;
+        const double rel = den > 0.0 ? fabs(qt[k] - qb[k]) * p4pf_rcp<false>(den) : 0.0;
         if (rel < best) { best = rel; join = k; }
     }
 #pragma unroll
@@ -328,8 +350,9 @@ PA_HD int p4pf_roots_sextic(const double (&a)[50], const p4pf_problem &pb, p4pf_
     for (int i = 0; i < 7; ++i) sc = fmax(sc, fabs(q[i]));
     if (!(sc > 0.0) || !(sc < 1.79e308)) return -1;
     double qr[7];
+    const double isc = p4pf_rcp(sc);
 #pragma unroll
-    for (int i = 0; i < 7; ++i) { q[i] /= sc; }
+    for (int i = 0; i < 7; ++i) { q[i] *= isc; }
 #pragma unroll
     for (int i = 0; i < 7; ++i) qr[i] = q[6 - i];
     // |L| <= 1 from q, |L| > 1 from the reversed polynomial (mu = 1/L in (-1, 1))
@@ -355,18 +378,18 @@ PA_HD int p4pf_roots_sextic(const double (&a)[50], const p4pf_problem &pb, p4pf_
         double L = lam[t];
         double S[5][5], y[4];
         // Newton on det P(L).  The eigenvector of the last evaluation is kept once the step is
-        // below 1e-13 relative (its error is of the order of that step); a step above 5 % means
+        // below 1e-12 relative (its error is of the order of that step); a step above 5 % means
         // the start was not in the basin of a root of det P and L is left where it is.
         bool resolve = true;
         for (int it = 0; it < 5; ++it) {
             p4pf_build_system(a, L, S);
             const double f = -p4pf_solve_system(S, y);      // = charpoly(L)
             const double df = poly_eval<9>(dp, L);
-            const double d = f / df;
+            const double d = f * p4pf_rcp(df);
             const double scale = fmax(1.0, fabs(L));
             if (!(d == d) || fabs(d) > 0.05 * scale) { resolve = false; break; }
             L -= d;
-            if (fabs(d) <= 1e-13 * scale) { resolve = false; break; }
+            if (fabs(d) <= 1e-12 * scale) { resolve = false; break; }
         }
         if (resolve) {
             p4pf_build_system(a, L, S);
