@@ -147,6 +147,22 @@ def test_p4pf_batch_random(ctx):
     assert agree >= gated - 3, (agree, gated)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("count", [1, 2, 3, 5, 7, 33, 130, 2051])
+def test_p4pf_batch_ragged_counts(ctx, count):
+    """Counts that do not fill the last pass of the elimination (four systems per wave pass) or
+    the last block: every problem must give exactly what it gives inside a large batch."""
+    m, M = synth.random_p4pf_problems(2051, 11)
+    nsol_all, f_all, R_all, t_all = ctx.p4pf_batch(m, M)
+    nsol, f, R, t = ctx.p4pf_batch(m[:count], M[:count])
+    assert np.array_equal(nsol, nsol_all[:count])
+    for i in range(count):
+        k = max(int(nsol[i]), 0)
+        assert np.array_equal(f[i, :k], f_all[i, :k])
+        assert np.array_equal(R[i, :k], R_all[i, :k])
+        assert np.array_equal(t[i, :k], t_all[i, :k])
+
+
 def test_p4pf_lapack_fixture(ctx):
     g = json.load(open(os.path.join(GOLD, "p4pf_lapack.json")))
     m = np.array([x["m2d"] for x in g]); M = np.array([x["M3D"] for x in g])

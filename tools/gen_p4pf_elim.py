@@ -142,6 +142,27 @@ def build_schedule():
             pat[r] = (pat[r] | union) - {c}
         # the pivot row (one of cand) retires; which one is dynamic, so structurally keep all
         stage2.append(dict(col=c, cand=sorted(cand), pattern=sorted(union)))
+    # Positions (p = 16 * slot + lane % 16): a stage-2 step whose only two candidate rows sit in
+    # the two slots of ONE lane needs no cross-lane traffic at all, so the leading two-candidate
+    # steps get their rows co-located by swapping positions.
+    used = set()
+    for st in stage2:
+        if len(st["cand"]) != 2:
+            break
+        ra, rb = st["cand"]
+        pa, pb = lane_of[ra], lane_of[rb]
+        if {pa, pb} & used:
+            break
+        if abs(pa - pb) != 16:
+            lo_row, hi_row = (ra, rb) if pa < pb else (rb, ra)
+            # move hi_row's partner into the other slot of hi_row's lane
+            target = lane_of[hi_row] - 16 if lane_of[hi_row] >= 16 else lane_of[hi_row] + 16
+            if target >= len(lanes_rows) or target in used:
+                break
+            other = next(r for r, p in lane_of.items() if p == target)
+            lane_of[other], lane_of[lo_row] = lane_of[lo_row], target
+        used |= {lane_of[ra], lane_of[rb]}
+        st["in_lane"] = True
     return dict(orig=orig, steps=steps, survivors=survivors, lanes_rows=lanes_rows, lane_of=lane_of, stage2=stage2)
 
 
@@ -313,7 +334,14 @@ def emit(sched):
         # their multipliers need no masking: whatever they accumulate stays in their own lane
         w(f"        const double m0 = r{c}_0 * nr, m1 = r{c}_1 * nr;")
         pat = st["pattern"]
-        if QUAD_BCAST == "bpermute":
+        if st.get("in_lane"):
+            # both candidates live in the two slots of one lane: the pivot row is the lane's own
+            # other slot; every other lane has exact zeros in this column, so its m0 = m1 = 0
+            for c2 in pat:
+                w(f"        const double e{c2} = sl ? r{c2}_1 : r{c2}_0;")
+                w(f"        r{c2}_0 = fma(m0, e{c2}, r{c2}_0);")
+                w(f"        r{c2}_1 = fma(m1, e{c2}, r{c2}_1);")
+        elif QUAD_BCAST == "bpermute":
             for i0 in range(0, len(pat), QUAD_CHUNK):
                 chunk = pat[i0:i0 + QUAD_CHUNK]
                 for c2 in chunk:
