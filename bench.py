@@ -135,7 +135,7 @@ def main():
         dom_ms, dom_flop = work[dom]
         tflops = dom_flop / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
         roofline = {"kernel": dom, "bound": "valu_fp64", "achieved": round(tflops, 3), "peak": FP64_VECTOR_PEAK_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(tflops / FP64_VECTOR_PEAK_TFLOPS, 4), "traffic": recorded_traffic(dom),
+                    "unit": "TFLOP/s", "frac": round(tflops / FP64_VECTOR_PEAK_TFLOPS, 4), "traffic": recorded_traffic(dom, hyps_rank / launches),
                     "launches": launches, "avg_launch_ms": round(dom_ms / launches, 4),
                     "kernel_ms_per_step": {k: round(v / args.steps, 3) for k, v in tim.items() if k.endswith("_ms")},
                     "kernel_tflops": {k: round(f / (ms * 1e-3) / 1e12, 3) for k, (ms, f) in work.items() if ms > 0},
@@ -290,14 +290,16 @@ def bench_dubrovnik(args):
     return 0
 
 
-def recorded_traffic(kernel):
+def recorded_traffic(kernel, hyps_per_launch):
     """HBM bytes per launch of `kernel` from the committed counter passes (FETCH_SIZE doubled
-    as measured for gfx950, plus WRITE_SIZE), or None when no record exists for it."""
+    as measured for gfx950, plus WRITE_SIZE), scaled from the recorded launch size to this run's
+    hypotheses per launch; None when no record exists for it."""
     path = os.path.join(ROOT, "profiles", "r1_traffic.json")
     try:
         with open(path) as f:
-            return json.load(f).get(kernel, {}).get("hbm_bytes_per_launch")
-    except (OSError, ValueError):
+            rec = json.load(f)
+        return rec[kernel]["hbm_bytes_per_launch"] * hyps_per_launch / rec["hypotheses_per_launch"]
+    except (OSError, ValueError, KeyError):
         return None
 
 

@@ -48,7 +48,9 @@ def load_template():
     return list(zip(out["ROW"], out["COL"], out["COEF"]))
 
 
-def build_schedule():
+def _build_schedule(forced=None):
+    """forced: optional list of (pivot row, column) pairs that replaces the greedy choice of
+    stage-1 pivots (used to re-order the pivots the greedy pass found)."""
     trip = load_template()
     orig = {r: {} for r in range(78)}            # original rows: col -> coef id
     for r, c, g in trip:
@@ -75,7 +77,13 @@ def build_schedule():
 
     while True:
         best = None
-        for c in elim_cols:
+        if forced is not None:
+            if len(steps) == len(forced):
+                break
+            pr, pc = forced[len(steps)]
+            assert rows[pr][pc][0] == "c" and pr not in modified
+            best = (None, pr, pc)
+        for c in ([] if forced is not None else elim_cols):
             if c in done:
                 continue
             rs = colrows(c)
@@ -164,6 +172,23 @@ def build_schedule():
         used |= {lane_of[ra], lane_of[rb]}
         st["in_lane"] = True
     return dict(orig=orig, steps=steps, survivors=survivors, lanes_rows=lanes_rows, lane_of=lane_of, stage2=stage2)
+
+
+# Order of the stage-1 pivots, as indices into the order the greedy pass finds them in.  Any
+# order is valid in which a pivot row is used before a column it has an entry in is eliminated
+# (it must still be in its original form); all of them do the same 395 multiply-adds.  This
+# one takes the pivot rows point by point (the template's coefficients come in four groups, one
+# per correspondence) and was picked by a random search over such orders for the smallest peak
+# of live matrix columns + live coefficients: 73 doubles per lane instead of the greedy
+# order's 89, which is what lets the kernel keep two rows per lane without spilling.
+STAGE1_ORDER = [3, 2, 8, 22, 19, 4, 5, 11, 9, 12, 17, 26, 20, 21, 36, 40, 16, 25, 30, 31, 33, 29, 18, 41, 37, 44, 47, 43, 45,
+                1, 23, 10, 24, 6, 7, 27, 28, 13, 34, 0, 38, 15, 39, 35, 42, 14, 32, 46, 48]
+
+
+def build_schedule():
+    greedy = _build_schedule()["steps"]
+    assert sorted(STAGE1_ORDER) == list(range(len(greedy)))
+    return _build_schedule([(greedy[i]["row"], greedy[i]["col"]) for i in STAGE1_ORDER])
 
 
 # ---------------------------------------------------------------------------------------------
