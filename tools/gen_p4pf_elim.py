@@ -36,7 +36,7 @@ RHS = list(range(78, 88))
 QUAD_BCAST = os.environ.get("P4PF_ELIM_QUAD_BCAST", "lds")   # pivot-row broadcast: "lds" (write + broadcast read) or "bpermute"
 SKIP = os.environ.get("P4PF_ELIM_SKIP", "")    # timing experiments only: "stage1" or "stage2" leaves that stage out
 PREFETCH = int(os.environ.get("P4PF_ELIM_PREFETCH", "0"))     # stage-1 steps between an LDS read and its first use (0..8 measured the same)
-QUAD_CHUNK = int(os.environ.get("P4PF_ELIM_QUAD_CHUNK", "8"))   # pivot-row entries in flight per group of broadcasts
+QUAD_CHUNK = int(os.environ.get("P4PF_ELIM_QUAD_CHUNK", "16"))   # pivot-row entries in flight per group of broadcasts
 
 
 def load_template():
