@@ -810,3 +810,5 @@ __global__ __launch_bounds__(256) void k_select(int limit, const int *__restrict
 }
 
 } // namespace pose_amd
+
+#include "score_mfma.h"

@@ -39,7 +39,10 @@ struct pose_amd_ctx {
     int64_t area_all = -1;         // coverage area of all matches (query_processor.cpp:154-169), -1 = not computed yet
     float xmax = 0, umax = 0;      // largest |coordinate| and largest |centred keypoint coordinate| of the query
     bool score_fp64_only = false;  // POSE_AMD_SCORE=fp64: skip the float32 screen (for A/B checks)
-    dev_buf projf;
+    bool score_mfma = true;        // POSE_AMD_SCORE=packed: never use the matrix-core screen
+    query_centre centre = {0, 0, 0, 0};   // centre of the 3-D points and largest |X - c| (NaN: unusable)
+    bool feat_ready = false;       // the query's feature image for the matrix-core screen is built
+    dev_buf projf, feat, vlist, vcount;
     // batch entry point: child contexts (one stream each) and their pinned result words
     std::vector<pose_amd_ctx *> lanes;
     // hypotheses
@@ -161,6 +164,7 @@ int pose_amd_create(int device, pose_amd_ctx **out)
     c->clock_khz = prop.clockRate;
     const char *sm = getenv("POSE_AMD_SCORE");
     c->score_fp64_only = sm && strcmp(sm, "fp64") == 0;
+    c->score_mfma = !(sm && strcmp(sm, "packed") == 0);
     if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
     for (int i = 0; i < 6; ++i)
         if ((e = hipEventCreate(&c->ev[i])) != hipSuccess) return bail("hipEventCreate", e);
@@ -181,7 +185,7 @@ void pose_amd_destroy(pose_amd_ctx *c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     dev_buf *bufs[] = {&c->kx, &c->ky, &c->X, &c->Y, &c->Z, &c->lindex, &c->cam_off, &c->cam_ids, &c->gain, &c->samples,
                        &c->sample_status, &c->proj, &c->pose, &c->nsol, &c->counts, &c->sel, &c->bitmaps, &c->areas,
-                       &c->maskw, &c->arows, &c->pstatus, &c->projf, &c->in0, &c->in1, &c->in2, &c->out0, &c->out1, &c->out2, &c->out3};
+                       &c->maskw, &c->arows, &c->pstatus, &c->projf, &c->feat, &c->vlist, &c->vcount, &c->in0, &c->in1, &c->in2, &c->out0, &c->out1, &c->out2, &c->out3};
     for (dev_buf *b : bufs) if (b->p) (void)hipFree(b->p);
     for (int i = 0; i < 6; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
     for (pose_amd_ctx *l : c->lanes) pose_amd_destroy(l);
@@ -294,6 +298,16 @@ int pose_amd_set_query(pose_amd_ctx *ctx, int n, const float *kx, const float *k
         xm = std::fmax(xm, a); um = std::fmax(um, u);
     }
     ctx->xmax = finite ? xm : NAN; ctx->umax = finite ? um * 1.000001f : NAN;
+    // centre of the 3-D points and the largest distance from it along an axis (matrix-core screen)
+    double sx = 0, sy = 0, sz = 0;
+    for (int i = 0; i < n; ++i) { sx += X[i]; sy += Y[i]; sz += Z[i]; }
+    const float cx = n ? (float)(sx / n) : 0.f, cy = n ? (float)(sy / n) : 0.f, cz = n ? (float)(sz / n) : 0.f;
+    double dm = 0;
+    for (int i = 0; i < n; ++i)
+        dm = std::fmax(dm, std::fmax(std::fabs((double)X[i] - cx), std::fmax(std::fabs((double)Y[i] - cy), std::fabs((double)Z[i] - cz))));
+    const bool cfin = finite && std::isfinite(cx) && std::isfinite(cy) && std::isfinite(cz) && std::isfinite(dm);
+    ctx->centre = query_centre{cx, cy, cz, cfin ? (float)(dm * 1.000001) : NAN};
+    ctx->feat_ready = false;
     ctx->solver = focal == 0.0 ? POSE_AMD_SOLVER_P4PF : POSE_AMD_SOLVER_P3P;
     ctx->has_cam = false;
     ctx->hyp_count = 0;
@@ -343,6 +357,14 @@ int pose_amd_compute_matrices_batch(pose_amd_ctx *ctx, int count, const double *
     return pose_amd_synchronize(ctx);
 }
 
+// The matrix-core screen counts only (no masks) and pays off for large launches; small ones
+// (early-exit chunks, single poses) keep the packed-float32 kernel, whose blocks adapt to them.
+static bool use_mfma_screen(const pose_amd_ctx *ctx, int nslots, bool want_masks)
+{
+    return ctx->score_mfma && !ctx->score_fp64_only && !want_masks && nslots >= 131072 && ctx->n <= MS_MAX_N - 32 &&
+           ctx->centre.xmaxc == ctx->centre.xmaxc && ctx->umax == ctx->umax;
+}
+
 // projf_ready: the float32 pose copies of these slots were already written by the solver kernels
 static int launch_score(pose_amd_ctx *ctx, int nslots, const double *proj_dev, const int *nsol_dev, int maxsol, double eps,
                         int *counts_dev, unsigned long long *mask_dev, int words_per_pose, bool projf_ready = false)
@@ -353,6 +375,24 @@ static int launch_score(pose_amd_ctx *ctx, int nslots, const double *proj_dev, c
     int spb = SCORE_SPB;
     while (spb > 8 && cdiv(nslots, spb) < (ctx->cus ? ctx->cus : 256) * 4) spb >>= 1;
     const dim3 grid(cdiv(nslots, spb)), block(SCORE_THREADS);
+    if (use_mfma_screen(ctx, nslots, mask_dev != nullptr)) {
+        int rc;
+        const int ntiles = cdiv(ctx->n, 32);
+        if (!ctx->feat_ready) {
+            if ((rc = ensure(ctx, ctx->feat, (size_t)ntiles * MS_TILE_BYTES))) return rc;
+            hipLaunchKernelGGL(k_make_feat, dim3(cdiv(ntiles * 32, 256)), dim3(256), 0, ctx->stream, q, ctx->centre, ntiles, (uint4 *)ctx->feat.p);
+            HIPCHK(ctx, hipGetLastError());
+            ctx->feat_ready = true;
+        }
+        if ((rc = ensure(ctx, ctx->vlist, (size_t)nslots * 4)) || (rc = ensure(ctx, ctx->vcount, 4))) return rc;
+        HIPCHK(ctx, hipMemsetAsync(ctx->vcount.p, 0, 4, ctx->stream));
+        hipLaunchKernelGGL(k_compact_valid, dim3(cdiv(nslots, MS_COMPACT_SLOTS)), dim3(256), 0, ctx->stream, nslots, nsol_dev, maxsol, (int *)ctx->vlist.p,
+                           (unsigned int *)ctx->vcount.p);
+        hipLaunchKernelGGL(k_score_mfma, dim3(cdiv(nslots, MS_POSES)), dim3(MS_THREADS), 0, ctx->stream, q, ctx->centre, (const uint4 *)ctx->feat.p,
+                           ntiles, proj_dev, (const int *)ctx->vlist.p, (const unsigned int *)ctx->vcount.p, eps, counts_dev);
+        HIPCHK(ctx, hipGetLastError());
+        return POSE_AMD_OK;
+    }
     if (!ctx->score_fp64_only) {
         if (!projf_ready) {
             int rc;
@@ -521,7 +561,7 @@ static int solve_and_score(pose_amd_ctx *ctx, uint32_t h0, uint32_t hc, int maxs
     int rc;
     // the solver kernels also write the float32 pose copies the scoring screen reads
     float *projf = nullptr;
-    if (!ctx->score_fp64_only) {
+    if (!ctx->score_fp64_only && !use_mfma_screen(ctx, (int)((size_t)hc * maxsol), false)) {
         if ((rc = ensure(ctx, ctx->projf, (size_t)hc * maxsol * 128))) return rc;
         projf = (float *)ctx->projf.p;
     }

@@ -1,0 +1,296 @@
+// Inlier counting with a matrix-core screen (gfx950, wave64).
+//
+// The x residual of the reprojection test (query_processor.cpp:112-121),
+//     rx = u * pz - px,   px = P0 X + P1 Y + P2 Z + P3,   pz = P8 X + P9 Y + P10 Z + P11,
+// is a bilinear form of eight per-correspondence features and eight per-pose numbers:
+//     rx = f . g,   f = (uX', uY', uZ', u, X', Y', Z', 1),   g = (P8, P9, P10, t2, -P0, -P1, -P2, -t0)
+// (X' = X - c is the correspondence's 3-D point relative to the query's centre c, t = P (c, 1)
+// the translation column moved accordingly), and pz = (X', Y', Z', 1) . (P8, P9, P10, t2).
+// A tile of 32 correspondences x 32 poses is therefore three v_mfma_f32_32x32x16_bf16: every
+// float32 operand is split into two bfloat16 parts (a = a_h + a_l + O(2^-18 a)); the K = 16
+// slots of the instructions hold f_h g_h | f_h g_l, then f_l g_h | (pz:) f'_h g'_h, f'_h g'_l.
+// Products of bfloat16 numbers are exact in float32, the accumulation is float32.
+//
+// As in the packed-float32 screen, the matrix result only ever certifies "outside": since
+// D = sqrt(rx^2 + ry^2) >= |rx|, a pair is certainly no inlier when |rx| > eps |pz| by more
+// than the error of both sides.  Every pair that is not certified is queued and decided by the
+// float64 test of k_score, so counts are identical to k_score's.
+//
+// Error bound.  e = 2^-24.  For |u| <= umax, |X' ...| <= xmax' (query-wide maxima) let
+//   Sz = (|P8| + |P9| + |P10|) xmax' + |t2|,  Sx = (|P0| + |P1| + |P2|) xmax' + |t0|,  T = umax Sz + Sx.
+//   float32 operands: each feature and each pose number carries one rounding   -> 2.01 e T
+//   dropped a_l b_l and the two split residuals: 3 * 2^-18 per product         -> 0.75 * 2^-16 T
+//   float32 accumulation of 24 exact products, any order, <= 2^-23 per step    -> 0.19 * 2^-16 T
+//   =>  |rx_m - rx| <= E = 1.01 * 2^-16 T.
+//   pz uses f'_h only (2^-9 per product) and both parts of g': |pz_m - pz| <= Ez = 1.01 * 2^-9 Sz.
+// Not an inlier if |rx_m| > eps |pz_m| + c with c = eps Ez + E.  The kernel evaluates the right-hand
+// side as one float32 fused multiply-add with eps and c rounded up and widened by (1 + 2^-22),
+// which covers the rounding of that operation.
+// A pose whose T is not finite or beyond 10^15 gets zero operands and B = inf (never certified).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace pose_amd {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float v2f32 __attribute__((ext_vector_type(2)));
+
+constexpr int MS_THREADS = 512;                    // 8 waves per block
+constexpr int MS_WAVES = MS_THREADS / 64;
+constexpr int MS_GROUPS = 2;                       // groups of 32 poses per wave, evaluated together tile by tile
+constexpr int MS_POSES = MS_WAVES * MS_GROUPS * 32;   // 512 poses per block
+constexpr int MS_TILE_BYTES = 1536;                // features of 32 correspondences: A1 | A2 (lanes 0..31) | A2 (lanes 32..63)
+constexpr int MS_CHUNK_TILES = 32;                 // tiles staged in LDS at a time (48 KB)
+constexpr int MS_QUEUE = 128;                      // queue entries per wave
+constexpr int MS_MAX_N = 1 << 17;                  // correspondence index bits in a queue entry
+constexpr float MS_PAD_U = 1.0e9f;                 // u of the padding correspondences (certified outside unless t2 == 0)
+
+// float32 -> bfloat16 bits, round to nearest even (finite inputs far from overflow)
+__device__ __forceinline__ unsigned bf16_rn(float x)
+{
+    const unsigned b = __float_as_uint(x);
+    return (b + 0x7fffu + ((b >> 16) & 1u)) >> 16;
+}
+__device__ __forceinline__ float bf16_as_float(unsigned h) { return __uint_as_float(h << 16); }
+// a = hi + lo + O(2^-18 a)
+__device__ __forceinline__ void bf16_split(float a, unsigned &hi, unsigned &lo)
+{
+    hi = bf16_rn(a);
+    lo = bf16_rn(a - bf16_as_float(hi));
+}
+
+struct query_centre { float cx, cy, cz, xmaxc; };   // centre of the 3-D points and max |X - c| over the query
+
+// Feature image of the query, 1536 bytes per tile of 32 correspondences (layout above).
+__global__ void k_make_feat(query_dev q, query_centre qc, int ntiles, uint4 *__restrict__ feat)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ntiles * 32) return;
+    float f[8];
+    if (i < q.n) {
+        const double u = -((double)q.kx[i] - (double)q.width / 2.0);
+        const double X = (double)q.X[i] - (double)qc.cx, Y = (double)q.Y[i] - (double)qc.cy, Z = (double)q.Z[i] - (double)qc.cz;
+        f[0] = (float)(u * X); f[1] = (float)(u * Y); f[2] = (float)(u * Z); f[3] = (float)u;
+        f[4] = (float)X; f[5] = (float)Y; f[6] = (float)Z; f[7] = 1.0f;
+    } else {
+        f[0] = f[1] = f[2] = 0.f; f[3] = MS_PAD_U; f[4] = f[5] = f[6] = 0.f; f[7] = 1.0f;
+    }
+    unsigned h[8], l[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) bf16_split(f[k], h[k], l[k]);
+    uint4 *t = feat + (size_t)(i >> 5) * (MS_TILE_BYTES / 16);
+    const int r = i & 31;
+    t[r] = make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
+    t[32 + r] = make_uint4(l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16));
+    const unsigned p0 = h[4] | (h[5] << 16), p1 = h[6] | (h[7] << 16);
+    t[64 + r] = make_uint4(p0, p1, p0, p1);
+}
+
+// Dense list of the valid pose slots (slot % maxsol < nsol[slot / maxsol]); order unspecified.
+// A block of 256 threads handles MS_COMPACT_SLOTS consecutive slots with one atomic reservation.
+constexpr int MS_COMPACT_SLOTS = 4096;
+__global__ __launch_bounds__(256) void k_compact_valid(int nslots, const int *__restrict__ nsol, int maxsol, int *__restrict__ vlist,
+                                                       unsigned int *__restrict__ counter)
+{
+    __shared__ int s_n[4];
+    __shared__ unsigned s_base;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int slot0 = blockIdx.x * MS_COMPACT_SLOTS + threadIdx.x * (MS_COMPACT_SLOTS / 256);
+    unsigned valid = 0;                                  // bit k: slot0 + k is valid
+#pragma unroll
+    for (int k = 0; k < MS_COMPACT_SLOTS / 256; ++k) {
+        const int slot = slot0 + k;
+        if (slot < nslots && (!nsol || (slot % maxsol) < nsol[slot / maxsol])) valid |= 1u << k;
+    }
+    const int mine = __popc(valid);
+    // exclusive prefix of `mine` inside the wave
+    int incl = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(incl, o);
+        if (lane >= o) incl += v;
+    }
+    if (lane == 63) s_n[wave] = incl;
+    __syncthreads();
+    if (threadIdx.x == 0) s_base = atomicAdd(counter, (unsigned)(s_n[0] + s_n[1] + s_n[2] + s_n[3]));
+    __syncthreads();
+    int off = (int)s_base + incl - mine;
+    for (int w = 0; w < 4; ++w) if (w < wave) off += s_n[w];
+#pragma unroll
+    for (int k = 0; k < MS_COMPACT_SLOTS / 256; ++k)
+        if ((valid >> k) & 1u) vlist[off++] = slot0 + k;
+}
+
+struct ms_pose_ops {
+    bf16x8 b1, b2, bz;
+    float c;              // additive slack of the pose: not an inlier if |rx_m| > eps_up |pz_m| + c
+};
+
+// Operands of one pose for the lane (pose j = lane % 32; the two halves of the wave hold
+// different K slots).  valid == false gives operands that certify every pair.
+__device__ __forceinline__ void ms_prepare(const double *__restrict__ proj, int slot, bool valid, const query_dev &q, const query_centre &qc,
+                                           double eps, bool upper, ms_pose_ops &o)
+{
+    double P[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) P[i] = valid ? proj[(size_t)slot * 12 + i] : 0.0;
+    const double cx = qc.cx, cy = qc.cy, cz = qc.cz, xm = qc.xmaxc, um = q.umax;
+    const double t0 = fma(P[0], cx, fma(P[1], cy, fma(P[2], cz, P[3])));
+    const double t2 = fma(P[8], cx, fma(P[9], cy, fma(P[10], cz, P[11])));
+    const double Sz = (fabs(P[8]) + fabs(P[9]) + fabs(P[10])) * xm + fabs(t2);
+    const double Sx = (fabs(P[0]) + fabs(P[1]) + fabs(P[2])) * xm + fabs(t0);
+    const double T = um * Sz + Sx;
+    const double E = 1.01 * 1.52587890625e-05 * T, Ez = 1.01 * 0.001953125 * Sz;
+    const double cd = (eps * Ez + E) * (1.0 + 2.384185791015625e-07);
+    float cf = (float)cd;
+    if ((double)cf < cd) cf = __uint_as_float(__float_as_uint(cf) + 1u);
+    const bool usable = T < 1.0e15;                                 // false for NaN as well
+    float g[8] = {(float)P[8], (float)P[9], (float)P[10], (float)t2, (float)-P[0], (float)-P[1], (float)-P[2], (float)-t0};
+    if (!valid) cf = -1.0f;                                         // rx = pz = 0: 0 > -1 certifies
+    else if (!usable) {
+        cf = __uint_as_float(0x7f800000u);                          // never certifies
+#pragma unroll
+        for (int k = 0; k < 8; ++k) g[k] = 0.f;
+    }
+    unsigned h[8], l[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) bf16_split(g[k], h[k], l[k]);
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    const u32x4 gh = {h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16)};
+    const u32x4 gl = {l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16)};
+    const u32x4 gz = {h[0] | (h[1] << 16), h[2] | (h[3] << 16), l[0] | (l[1] << 16), l[2] | (l[3] << 16)};
+    const u32x4 zero = {0u, 0u, 0u, 0u};
+    o.b1 = __builtin_bit_cast(bf16x8, upper ? gl : gh);
+    o.b2 = __builtin_bit_cast(bf16x8, upper ? zero : gh);
+    o.bz = __builtin_bit_cast(bf16x8, upper ? gz : zero);
+    o.c = cf;
+}
+
+// The float64 decision of k_score for one (pose, correspondence) pair.
+__device__ __forceinline__ bool ms_exact_inlier(const query_dev &q, const double *__restrict__ proj, int slot, int idx, double eps)
+{
+    if (idx >= q.n) return false;
+    const double hw = (double)q.width / 2.0, hh = (double)q.height / 2.0;
+    const double *__restrict__ P = proj + (size_t)slot * 12;
+    const double u = -((double)q.kx[idx] - hw), v = -((double)q.ky[idx] - hh);
+    const double X = (double)q.X[idx], Y = (double)q.Y[idx], Z = (double)q.Z[idx];
+    const double px = fma(P[0], X, fma(P[1], Y, fma(P[2], Z, P[3])));
+    const double py = fma(P[4], X, fma(P[5], Y, fma(P[6], Z, P[7])));
+    const double pz = fma(P[8], X, fma(P[9], Y, fma(P[10], Z, P[11])));
+    const double rx = fma(u, pz, -px), ry = fma(v, pz, -py);
+    const double d2 = fma(ry, ry, rx * rx);
+    const double te = eps * pz;
+    return d2 < te * te;
+}
+
+// counts[slot] for the valid slots listed in vlist[0 .. *nvalid_p).  One block takes MS_POSES
+// consecutive entries of the list; wave w owns the groups 2w and 2w + 1 of 32 poses each and keeps
+// their operands in registers while the block walks over the correspondences in chunks of
+// MS_CHUNK_TILES tiles staged in LDS.  Both groups share the tile's feature operands; the six
+// matrix instructions of a tile are issued back to back so that the vector work on the first
+// group's result overlaps the second group's products.
+__global__ __launch_bounds__(MS_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_score_mfma(
+    query_dev q, query_centre qc, const uint4 *__restrict__ feat, int ntiles, const double *__restrict__ proj,
+    const int *__restrict__ vlist, const unsigned int *__restrict__ nvalid_p, double eps, int *__restrict__ counts)
+{
+    __shared__ uint4 s_feat[MS_CHUNK_TILES * MS_TILE_BYTES / 16];
+    __shared__ int s_cnt[MS_POSES];
+    __shared__ int s_slot[MS_POSES];
+    __shared__ unsigned s_queue[MS_WAVES][MS_QUEUE];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const bool upper = lane >= 32;
+    const int nvalid = (int)*nvalid_p;
+    const int first = blockIdx.x * MS_POSES;
+    if (first >= nvalid) return;                         // whole blocks leave together
+    const int nblk = min(MS_POSES, nvalid - first);
+    for (int i = tid; i < MS_POSES; i += MS_THREADS) {
+        s_cnt[i] = 0;
+        s_slot[i] = i < nblk ? vlist[first + i] : -1;
+    }
+    __syncthreads();
+    ms_pose_ops ops[MS_GROUPS];
+    const int pl0 = wave * (32 * MS_GROUPS) + (lane & 31);    // the lane's pose of group 0; group g: + 32 g
+    const bool live = wave * (32 * MS_GROUPS) < nblk;         // wave-uniform: the wave has at least one pose
+#pragma unroll
+    for (int g = 0; g < MS_GROUPS; ++g) {
+        const int pl = pl0 + 32 * g;
+        ms_prepare(proj, pl < nblk ? s_slot[pl] : 0, pl < nblk, q, qc, eps, upper, ops[g]);
+    }
+    // eps rounded up and widened for the float32 evaluation of eps |pz| + c
+    const double epd = eps * (1.0 + 2.384185791015625e-07);
+    float epf = (float)epd;
+    if ((double)epf < epd) epf = __uint_as_float(__float_as_uint(epf) + 1u);
+    unsigned *queue = s_queue[wave];
+    int qn = 0;                                          // wave-uniform number of queued pairs
+    const unsigned long long below = (1ull << lane) - 1ull;
+
+    auto drain = [&](int count) {                        // decides queue[0 .. count), count <= 64
+        if (lane < count) {
+            const unsigned e = queue[lane];
+            const int pl = (int)(e >> 17), idx = (int)(e & (MS_MAX_N - 1));
+            if (ms_exact_inlier(q, proj, s_slot[pl], idx, eps)) atomicAdd(&s_cnt[pl], 1);
+        }
+    };
+    // screens one 32 x 32 result and queues what it cannot certify
+    auto screen = [&](const f32x16 &rx, const f32x16 &pz, float c, int pl, int mbase) {
+        unsigned long long open[16];
+        unsigned long long any = 0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float lim = fmaf(fabsf(pz[r]), epf, c);
+            open[r] = ~__ballot(fabsf(rx[r]) > lim);
+            any |= open[r];
+        }
+        if (any) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const unsigned long long m = open[r];
+                if (!m) continue;
+                // D[i][j]: j = lane % 32, i = 8 (r / 4) + 4 (lane / 32) + r % 4
+                if ((m >> lane) & 1ull)
+                    queue[qn + __popcll(m & below)] = ((unsigned)pl << 17) | (unsigned)(mbase + 8 * (r / 4) + (r % 4));
+                qn += __popcll(m);
+                if (qn >= 64) {
+                    __builtin_amdgcn_wave_barrier();
+                    drain(64);
+                    __builtin_amdgcn_wave_barrier();
+                    const unsigned keep = lane < qn - 64 ? queue[64 + lane] : 0u;
+                    __builtin_amdgcn_wave_barrier();
+                    if (lane < qn - 64) queue[lane] = keep;
+                    qn -= 64;
+                }
+            }
+        }
+    };
+
+    for (int chunk0 = 0; chunk0 < ntiles; chunk0 += MS_CHUNK_TILES) {
+        const int ct = min(MS_CHUNK_TILES, ntiles - chunk0);
+        __syncthreads();                                 // everybody is done with the previous chunk
+        for (int i = tid; i < ct * (MS_TILE_BYTES / 16); i += MS_THREADS) s_feat[i] = feat[(size_t)chunk0 * (MS_TILE_BYTES / 16) + i];
+        __syncthreads();
+        if (!live) continue;
+        for (int t = 0; t < ct; ++t) {
+            const uint4 *tf = s_feat + t * (MS_TILE_BYTES / 16);
+            const bf16x8 a1 = __builtin_bit_cast(bf16x8, tf[lane & 31]);
+            const bf16x8 a2 = __builtin_bit_cast(bf16x8, tf[32 + lane]);
+            f32x16 rx0 = {}, pz0 = {}, rx1 = {}, pz1 = {};
+            rx0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, ops[0].b1, rx0, 0, 0, 0);
+            pz0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, ops[0].bz, pz0, 0, 0, 0);
+            rx0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, ops[0].b2, rx0, 0, 0, 0);
+            rx1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, ops[1].b1, rx1, 0, 0, 0);
+            pz1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, ops[1].bz, pz1, 0, 0, 0);
+            rx1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, ops[1].b2, rx1, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            const int mbase = (chunk0 + t) * 32 + (upper ? 4 : 0);
+            screen(rx0, pz0, ops[0].c, pl0, mbase);
+            screen(rx1, pz1, ops[1].c, pl0 + 32, mbase);
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    drain(qn);
+    __syncthreads();
+    for (int i = tid; i < nblk; i += MS_THREADS) counts[s_slot[i]] = s_cnt[i];
+}
+
+} // namespace pose_amd
