@@ -361,7 +361,8 @@ int pose_amd_compute_matrices_batch(pose_amd_ctx *ctx, int count, const double *
 // (early-exit chunks, single poses) keep the packed-float32 kernel, whose blocks adapt to them.
 static bool use_mfma_screen(const pose_amd_ctx *ctx, int nslots, bool want_masks)
 {
-    return ctx->score_mfma && !ctx->score_fp64_only && !want_masks && nslots >= 131072 && ctx->n <= MS_MAX_N - 32 &&
+    static const int min_slots = getenv("POSE_AMD_MFMA_MIN_SLOTS") ? atoi(getenv("POSE_AMD_MFMA_MIN_SLOTS")) : 131072;
+    return ctx->score_mfma && !ctx->score_fp64_only && !want_masks && nslots >= min_slots && ctx->n <= MS_MAX_N - 32 &&
            ctx->centre.xmaxc == ctx->centre.xmaxc && ctx->umax == ctx->umax;
 }
 

@@ -60,6 +60,18 @@ __device__ __forceinline__ void bf16_split(float a, unsigned &hi, unsigned &lo)
     lo = bf16_rn(a - bf16_as_float(hi));
 }
 
+// Scheduling request for a region that holds three matrix instructions and one result's screen
+// (32 vector instructions): one matrix instruction, then the vector work that fits in its shadow.
+#define MS_INTERLEAVE()                                      \
+    do {                                                     \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   \
+        __builtin_amdgcn_sched_group_barrier(0x002, 10, 0);  \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   \
+        __builtin_amdgcn_sched_group_barrier(0x002, 10, 0);  \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   \
+        __builtin_amdgcn_sched_group_barrier(0x002, 12, 0);  \
+    } while (0)
+
 struct query_centre { float cx, cy, cz, xmaxc; };   // centre of the 3-D points and max |X - c| over the query
 
 // Feature image of the query, 1536 bytes per tile of 32 correspondences (layout above).
@@ -147,8 +159,16 @@ __device__ __forceinline__ void ms_prepare(const double *__restrict__ proj, int 
     if ((double)cf < cd) cf = __uint_as_float(__float_as_uint(cf) + 1u);
     const bool usable = T < 1.0e15;                                 // false for NaN as well
     float g[8] = {(float)P[8], (float)P[9], (float)P[10], (float)t2, (float)-P[0], (float)-P[1], (float)-P[2], (float)-t0};
-    if (!valid) cf = -1.0f;                                         // rx = pz = 0: 0 > -1 certifies
-    else if (!usable) {
+    // A pose with a NaN or an infinity among its entries has no inlier by the float64 test (every
+    // comparison it makes is false), so all of its pairs are certified like those of an empty slot.
+    double fin = 0.0;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) fin = fma(P[i], 0.0, fin);
+    if (!valid || !(fin == 0.0)) {
+        cf = -1.0f;                                                 // rx = pz = 0: 0 > -1 certifies
+#pragma unroll
+        for (int k = 0; k < 8; ++k) g[k] = 0.f;
+    } else if (!usable) {
         cf = __uint_as_float(0x7f800000u);                          // never certifies
 #pragma unroll
         for (int k = 0; k < 8; ++k) g[k] = 0.f;
@@ -197,7 +217,7 @@ __global__ __launch_bounds__(MS_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
     __shared__ uint4 s_feat[MS_CHUNK_TILES * MS_TILE_BYTES / 16];
     __shared__ int s_cnt[MS_POSES];
     __shared__ int s_slot[MS_POSES];
-    __shared__ unsigned s_queue[MS_WAVES][MS_QUEUE];
+    __shared__ unsigned s_queue[MS_WAVES][MS_QUEUE + 64];   // + one scratch word per lane
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const bool upper = lane >= 32;
     const int nvalid = (int)*nvalid_p;
@@ -223,7 +243,6 @@ __global__ __launch_bounds__(MS_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
     if ((double)epf < epd) epf = __uint_as_float(__float_as_uint(epf) + 1u);
     unsigned *queue = s_queue[wave];
     int qn = 0;                                          // wave-uniform number of queued pairs
-    const unsigned long long below = (1ull << lane) - 1ull;
 
     auto drain = [&](int count) {                        // decides queue[0 .. count), count <= 64
         if (lane < count) {
@@ -233,32 +252,43 @@ __global__ __launch_bounds__(MS_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
         }
     };
     // screens one 32 x 32 result and queues what it cannot certify
+    const unsigned qaddr = (unsigned)(size_t)queue;      // LDS byte address of the wave's queue
+    const unsigned dummy = qaddr + (MS_QUEUE + lane) * 4;   // where lanes without a pair to queue write
     auto screen = [&](const f32x16 &rx, const f32x16 &pz, float c, int pl, int mbase) {
         unsigned long long open[16];
-        unsigned long long any = 0;
+        unsigned long long any4[4] = {0, 0, 0, 0};
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const float lim = fmaf(fabsf(pz[r]), epf, c);
             open[r] = ~__ballot(fabsf(rx[r]) > lim);
-            any |= open[r];
+            any4[r / 4] |= open[r];
         }
-        if (any) {
+        if ((any4[0] | any4[1]) | (any4[2] | any4[3])) {
+            const unsigned ent = ((unsigned)pl << 17) | (unsigned)mbase;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const unsigned long long m = open[r];
-                if (!m) continue;
-                // D[i][j]: j = lane % 32, i = 8 (r / 4) + 4 (lane / 32) + r % 4
-                if ((m >> lane) & 1ull)
-                    queue[qn + __popcll(m & below)] = ((unsigned)pl << 17) | (unsigned)(mbase + 8 * (r / 4) + (r % 4));
-                qn += __popcll(m);
-                if (qn >= 64) {
-                    __builtin_amdgcn_wave_barrier();
-                    drain(64);
-                    __builtin_amdgcn_wave_barrier();
-                    const unsigned keep = lane < qn - 64 ? queue[64 + lane] : 0u;
-                    __builtin_amdgcn_wave_barrier();
-                    if (lane < qn - 64) queue[lane] = keep;
-                    qn -= 64;
+            for (int r4 = 0; r4 < 4; ++r4) {
+                if (!any4[r4]) continue;
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {
+                    const int r = 4 * r4 + rr;
+                    const unsigned long long m = open[r];
+                    if (!m) continue;
+                    // D[i][j]: j = lane % 32, i = 8 (r / 4) + 4 (lane / 32) + r % 4.  Every lane stores;
+                    // the ones without a pair store to a scratch word of their own.
+                    const unsigned pos = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+                    const bool mine = (m >> lane) & 1ull;
+                    const unsigned addr = mine ? qaddr + ((unsigned)qn + pos) * 4u : dummy;
+                    *reinterpret_cast<__attribute__((address_space(3))) unsigned *>((uintptr_t)addr) = ent + (unsigned)(8 * r4 + rr);
+                    qn = __builtin_amdgcn_readfirstlane(qn + __popcll(m));
+                    if (qn >= 64) {
+                        __builtin_amdgcn_wave_barrier();
+                        drain(64);
+                        __builtin_amdgcn_wave_barrier();
+                        const unsigned keep = lane < qn - 64 ? queue[64 + lane] : 0u;
+                        __builtin_amdgcn_wave_barrier();
+                        if (lane < qn - 64) queue[lane] = keep;
+                        qn -= 64;
+                    }
                 }
             }
         }
@@ -270,22 +300,28 @@ __global__ __launch_bounds__(MS_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
         for (int i = tid; i < ct * (MS_TILE_BYTES / 16); i += MS_THREADS) s_feat[i] = feat[(size_t)chunk0 * (MS_TILE_BYTES / 16) + i];
         __syncthreads();
         if (!live) continue;
+        // Skewed by half a step so that matrix and vector work interleave inside the wave: while
+        // group 0's products of tile t are in the matrix pipe the wave screens group 1's result of
+        // tile t - 1, and while group 1's products of tile t are in flight it screens group 0's.
+        f32x16 rx0, pz0, rx1 = {}, pz1 = {};
         for (int t = 0; t < ct; ++t) {
             const uint4 *tf = s_feat + t * (MS_TILE_BYTES / 16);
             const bf16x8 a1 = __builtin_bit_cast(bf16x8, tf[lane & 31]);
             const bf16x8 a2 = __builtin_bit_cast(bf16x8, tf[32 + lane]);
-            f32x16 rx0 = {}, pz0 = {}, rx1 = {}, pz1 = {};
-            rx0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, ops[0].b1, rx0, 0, 0, 0);
-            pz0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, ops[0].bz, pz0, 0, 0, 0);
-            rx0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, ops[0].b2, rx0, 0, 0, 0);
-            rx1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, ops[1].b1, rx1, 0, 0, 0);
-            pz1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, ops[1].bz, pz1, 0, 0, 0);
-            rx1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, ops[1].b2, rx1, 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
             const int mbase = (chunk0 + t) * 32 + (upper ? 4 : 0);
+            const f32x16 zero = {};
+            rx0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, ops[0].b1, zero, 0, 0, 0);
+            pz0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, ops[0].bz, zero, 0, 0, 0);
+            rx0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, ops[0].b2, rx0, 0, 0, 0);
+            if (t > 0) screen(rx1, pz1, ops[1].c, pl0 + 32, mbase - 32);
+            MS_INTERLEAVE();
+            rx1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, ops[1].b1, zero, 0, 0, 0);
+            pz1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, ops[1].bz, zero, 0, 0, 0);
+            rx1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, ops[1].b2, rx1, 0, 0, 0);
             screen(rx0, pz0, ops[0].c, pl0, mbase);
-            screen(rx1, pz1, ops[1].c, pl0 + 32, mbase);
+            MS_INTERLEAVE();
         }
+        screen(rx1, pz1, ops[1].c, pl0 + 32, (chunk0 + ct - 1) * 32 + (upper ? 4 : 0));
     }
     __builtin_amdgcn_wave_barrier();
     drain(qn);
