@@ -127,10 +127,14 @@ def main():
         # library on its own stream around each kernel, averaged over the launches of the timed steps.
         launches = max(int(tim["launches"]), 1)
         hyps_rank = H * args.steps
+        # large launches are scored by the matrix-core screen, small ones by the packed-float32 one
+        maxsol = 4 if args.known_focal else 10
+        score_kernel = ("k_score_mfma" if hyps_rank // launches * maxsol >= 131072 and
+                        os.environ.get("POSE_AMD_SCORE") not in ("packed", "fp64") else "k_score_screen")
         work = {"k_solve_p3p": (tim["solve_ms"], hyps_rank * P3P_FLOP_PER_HYP)} if args.known_focal else {}
         work.update({"k_p4pf_elim": (tim["elim_ms"], hyps_rank * ELIM_FLOP_PER_HYP),
                 "k_p4pf_finish": (tim["finish_ms"], hyps_rank * FINISH_FLOP_PER_HYP),
-                "k_score_screen": (tim["score_ms"], poses * args.matches * SCORE_FLOP_PER_PAIR)})
+                score_kernel: (tim["score_ms"], poses * args.matches * SCORE_FLOP_PER_PAIR)})
         dom = max(work, key=lambda k: work[k][0])
         dom_ms, dom_flop = work[dom]
         tflops = dom_flop / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0

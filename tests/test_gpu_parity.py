@@ -458,6 +458,49 @@ def test_score_screen_equals_float64_kernel(ctx):
                 assert c0.max() > 0.1 * n and c0.min() < 0.05 * n
 
 
+def test_score_matrix_core_screen_equals_float64_kernel(ctx):
+    """Launches large enough for the matrix-core screen (no masks, >= 131072 poses) must count
+    exactly what the float64-only kernel counts: poses at all distances from the truth, world
+    coordinates far from the origin, odd sizes, and poses with NaN, infinite, huge, tiny and zero
+    entries."""
+    from pose_estimation_amd import Context
+    os.environ["POSE_AMD_SCORE"] = "fp64"
+    try:
+        ref_ctx = Context(0)
+    finally:
+        del os.environ["POSE_AMD_SCORE"]
+    rng = np.random.default_rng(21)
+    with ref_ctx:
+        for n, shift in ((4099, 0.0), (1000, 5000.0), (63, 0.0)):
+            q = synth.make_query(n, 0.6, 9 + n, noise_px=0.7)
+            q["X"] = (q["X"] + np.float32(shift)).astype(np.float32)
+            Ctrue = q["C_true"] + np.array([shift, 0.0, 0.0])
+            base = []
+            for i in range(2048):
+                s = 10.0 ** rng.uniform(-9, 0.5)
+                base.append(O.compute_matrices(q["f_true"] * (1 + s * rng.normal() * 1e-2), Ctrue + s * rng.normal(size=3),
+                                               q["Rc_true"] @ synth.small_rotation(rng, s * 1e-2)))
+            base = np.array(base)
+            P = np.tile(base, (65, 1, 1))[:131072 + 777].copy()
+            # perturb the copies so that they are distinct poses
+            P *= (1.0 + 1e-7 * rng.normal(size=(len(P), 1, 1)))
+            P[5] = np.nan
+            P[6, 2, 3] = np.inf
+            P[7] *= 1e20
+            P[8] *= 1e-20
+            P[9] = 0.0
+            P[10, 0, 0] = np.nan
+            P[11, 2] = 0.0                      # pz == 0 for every correspondence
+            P[12] *= -1.0
+            for c in (ctx, ref_ctx):
+                upload(c, q)
+            for eps in (0.5, 0.37):
+                c1 = ctx.score_batch(P, eps, want_masks=False)
+                c0 = ref_ctx.score_batch(P, eps, want_masks=False)
+                assert np.array_equal(c1, c0)
+                assert c0.max() > 0.1 * n and c0[5] == 0 and c0[6] == 0 and c0[10] == 0
+
+
 def test_ransac_large_query_config5_shape(ctx):
     """BASELINE config 5 in miniature: 100 000 matches, 1 % inliers, a hypothesis range split in
     two halves whose packed keys are max-reduced (what the ranks do) equals the whole range."""
