@@ -21,8 +21,9 @@
 //   float32 operands: each feature and each pose number carries one rounding   -> 2.01 e T
 //   dropped a_l b_l and the two split residuals: 3 * 2^-18 per product         -> 0.75 * 2^-16 T
 //   float32 accumulation of 24 exact products, any order, <= 2^-23 per step    -> 0.19 * 2^-16 T
-//   =>  |rx_m - rx| <= E = 1.01 * 2^-16 T.
-//   pz uses f'_h only (2^-9 per product) and both parts of g': |pz_m - pz| <= Ez = 1.01 * 2^-9 Sz.
+//   =>  |rx_m - rx| <= 0.95 * 2^-16 T; the kernel uses E = 1.25 * 2^-16 T, which leaves room for an
+//   accumulator that is twice as coarse as assumed.
+//   pz uses f'_h only (2^-9 per product) and both parts of g': |pz_m - pz| <= Ez = 1.25 * 2^-9 Sz.
 // Not an inlier if |rx_m| > eps |pz_m| + c with c = eps Ez + E.  The kernel evaluates the right-hand
 // side as one float32 fused multiply-add with eps and c rounded up and widened by (1 + 2^-22),
 // which covers the rounding of that operation.
@@ -153,7 +154,7 @@ __device__ __forceinline__ void ms_prepare(const double *__restrict__ proj, int 
     const double Sz = (fabs(P[8]) + fabs(P[9]) + fabs(P[10])) * xm + fabs(t2);
     const double Sx = (fabs(P[0]) + fabs(P[1]) + fabs(P[2])) * xm + fabs(t0);
     const double T = um * Sz + Sx;
-    const double E = 1.01 * 1.52587890625e-05 * T, Ez = 1.01 * 0.001953125 * Sz;
+    const double E = 1.25 * 1.52587890625e-05 * T, Ez = 1.25 * 0.001953125 * Sz;
     const double cd = (eps * Ez + E) * (1.0 + 2.384185791015625e-07);
     float cf = (float)cd;
     if ((double)cf < cd) cf = __uint_as_float(__float_as_uint(cf) + 1u);

@@ -81,6 +81,30 @@ int main()
         bad += s != hd[l * 16 + r];
     }
     printf("layout check: %d mismatches of 1024\n", bad);
+    // accumulation accuracy: random bf16 operands with a wide spread of magnitudes, error of the
+    // float32 result against exact arithmetic in units of 2^-24 * sum |a_k b_k|
+    {
+        double worst = 0;
+        for (int trial = 0; trial < 200; ++trial) {
+            for (int i = 0; i < 512; ++i) {
+                ha[i] = bf((float)((rand() % 2001 - 1000) / 1000.0 * pow(2.0, rand() % 25 - 12)));
+                hb[i] = bf((float)((rand() % 2001 - 1000) / 1000.0 * pow(2.0, rand() % 25 - 12)));
+            }
+            CHECK(hipMemcpy(da, ha, 1024, hipMemcpyHostToDevice)); CHECK(hipMemcpy(db, hb, 1024, hipMemcpyHostToDevice));
+            k_one<<<1, 64>>>(da, db, dd);
+            CHECK(hipMemcpy(hd, dd, 4096, hipMemcpyDeviceToHost));
+            for (int l = 0; l < 64; ++l) for (int r = 0; r < 16; ++r) {
+                const int j = l % 32, i = 8 * (r / 4) + 4 * (l / 32) + r % 4;
+                double s = 0, sa = 0;
+                for (int k = 0; k < 16; ++k) {
+                    const double t = (double)fb(ha[(i + 32 * (k / 8)) * 8 + k % 8]) * (double)fb(hb[(j + 32 * (k / 8)) * 8 + k % 8]);
+                    s += t; sa += fabs(t);
+                }
+                if (sa > 0) worst = fmax(worst, fabs((double)hd[l * 16 + r] - s) / (sa * 5.9604644775390625e-08));
+            }
+        }
+        printf("accumulation of 16 products: worst error %.2f x 2^-24 x sum|a b|  (model allows 32)\n", worst);
+    }
     const int blocks = 256 * 8, iters = 4000;
     float *dout; CHECK(hipMalloc(&dout, blocks * 256 * 4));
     hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
