@@ -43,6 +43,14 @@ struct pose_amd_ctx {
     query_centre centre = {0, 0, 0, 0};   // centre of the 3-D points and largest |X - c| (NaN: unusable)
     bool feat_ready = false;       // the query's feature image for the matrix-core screen is built
     dev_buf projf, feat, vlist, vcount;
+    // second stream for large fixed-budget chunks: the chunk is cut in two halves whose kernels
+    // overlap (the elimination is bound by the LDS pipe, scoring and the eigen step by the vector
+    // and matrix pipes), with scratch buffers and timing events of its own
+    bool overlap = false;          // POSE_AMD_OVERLAP=1 enables it (+4 % throughput; per-kernel times then include the sharing)
+    hipStream_t stream2 = nullptr;
+    hipEvent_t ev2[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // [3] = fork, [5] = join
+    dev_buf arows2, pstatus2, vlist2, vcount2;
+    bool side_used = false;        // the last solve_and_score call used the second stream
     // batch entry point: child contexts (one stream each) and their pinned result words
     std::vector<pose_amd_ctx *> lanes;
     // hypotheses
@@ -112,26 +120,41 @@ static query_dev make_query(const pose_amd_ctx *c)
 
 static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 
+// Stream, scratch buffers and timing events a group of launches uses (the context's own, or
+// those of its second stream).
+struct lane_io {
+    hipStream_t stream;
+    dev_buf *arows, *pstatus, *vlist, *vcount;
+    hipEvent_t *ev;
+};
+static lane_io main_io(pose_amd_ctx *c) { return lane_io{c->stream, &c->arows, &c->pstatus, &c->vlist, &c->vcount, c->ev}; }
+static lane_io side_io(pose_amd_ctx *c) { return lane_io{c->stream2, &c->arows2, &c->pstatus2, &c->vlist2, &c->vcount2, c->ev2}; }
+
 // P4Pf minimal solves for `count` hypotheses: cooperative elimination, then per-lane eigen
 // step and pose recovery.  Exactly one of (samples) / (m2d, M3D) is given.
-static int launch_p4pf(pose_amd_ctx *ctx, uint32_t count, const uint32_t *samples, const double *m2d, const double *M3D,
+static int launch_p4pf(pose_amd_ctx *ctx, const lane_io &io, uint32_t count, const uint32_t *samples, const double *m2d, const double *M3D,
                        double *proj, double *pose, int *nsol, double *fo, double *Ro, double *to, float *projf = nullptr, double eps = 0.0)
 {
     int rc;
-    if ((rc = ensure(ctx, ctx->arows, (size_t)count * P4PF_TAIL * 8)) || (rc = ensure(ctx, ctx->pstatus, (size_t)count * 4))) return rc;
+    if ((rc = ensure(ctx, *io.arows, (size_t)count * P4PF_TAIL * 8)) || (rc = ensure(ctx, *io.pstatus, (size_t)count * 4))) return rc;
     const query_dev q = make_query(ctx);
     // 32 systems per block amortise the coefficient phase; launches too small to give every
     // wave slot of the chip a block that way use smaller batches (multiples of 4: the systems
-    // one pass of the wave eliminates)
+    // one pass of the wave eliminates).  One batch per block: blocks that start at different
+    // times keep the waves of a compute unit in different phases (coefficients, stage 1 on the
+    // vector pipe, stage 2 on the LDS pipe), which measures 9 % faster than resident blocks that
+    // loop in step -- except when the chunk is split over two streams, where two grids of
+    // resident blocks interleave best.
     const int slots = (ctx->cus ? ctx->cus : 256) * 8;
     int batch = 4 * cdiv(cdiv(count, slots), 4);
     batch = std::max(4, std::min(batch, ELIM_BATCH));
-    hipLaunchKernelGGL(k_p4pf_elim, dim3(std::min(cdiv(count, batch), slots)), dim3(64), 0, ctx->stream, q, count, samples, m2d, M3D,
-                       (double *)ctx->arows.p, (int *)ctx->pstatus.p, batch);
+    const int nbatch = cdiv(count, batch);
+    hipLaunchKernelGGL(k_p4pf_elim, dim3(ctx->side_used ? std::min(nbatch, slots) : nbatch), dim3(64), 0, io.stream, q, count, samples, m2d, M3D,
+                       (double *)io.arows->p, (int *)io.pstatus->p, batch);
     HIPCHK(ctx, hipGetLastError());
-    HIPCHK(ctx, hipEventRecord(ctx->ev[4], ctx->stream));     // end of the elimination kernel, for the per-kernel timing
-    hipLaunchKernelGGL(k_p4pf_finish, dim3(cdiv(count, 64)), dim3(64), 0, ctx->stream, q, count, samples, m2d, M3D,
-                       (const double *)ctx->arows.p, (const int *)ctx->pstatus.p, proj, pose, nsol, fo, Ro, to, projf, eps);
+    HIPCHK(ctx, hipEventRecord(io.ev[4], io.stream));     // end of the elimination kernel, for the per-kernel timing
+    hipLaunchKernelGGL(k_p4pf_finish, dim3(cdiv(count, 64)), dim3(64), 0, io.stream, q, count, samples, m2d, M3D,
+                       (const double *)io.arows->p, (const int *)io.pstatus->p, proj, pose, nsol, fo, Ro, to, projf, eps);
     HIPCHK(ctx, hipGetLastError());
     return POSE_AMD_OK;
 }
@@ -168,6 +191,8 @@ int pose_amd_create(int device, pose_amd_ctx **out)
     if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
     for (int i = 0; i < 6; ++i)
         if ((e = hipEventCreate(&c->ev[i])) != hipSuccess) return bail("hipEventCreate", e);
+    const char *ov = getenv("POSE_AMD_OVERLAP");
+    c->overlap = ov && strcmp(ov, "1") == 0;
     // co-occurrence gain table of the advanced sampler (query_processor_advanced.cpp:391-392)
     std::vector<double> gain(MAXCAM + 1);
     for (int cs = 0; cs <= MAXCAM; ++cs) gain[cs] = 1.0 / (1.0 + std::exp(-(double)((float)cs / 5.0f)));
@@ -185,9 +210,11 @@ void pose_amd_destroy(pose_amd_ctx *c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     dev_buf *bufs[] = {&c->kx, &c->ky, &c->X, &c->Y, &c->Z, &c->lindex, &c->cam_off, &c->cam_ids, &c->gain, &c->samples,
                        &c->sample_status, &c->proj, &c->pose, &c->nsol, &c->counts, &c->sel, &c->bitmaps, &c->areas,
-                       &c->maskw, &c->arows, &c->pstatus, &c->projf, &c->feat, &c->vlist, &c->vcount, &c->in0, &c->in1, &c->in2, &c->out0, &c->out1, &c->out2, &c->out3};
+                       &c->maskw, &c->arows, &c->pstatus, &c->projf, &c->feat, &c->vlist, &c->vcount, &c->arows2, &c->pstatus2, &c->vlist2, &c->vcount2, &c->in0, &c->in1, &c->in2, &c->out0, &c->out1, &c->out2, &c->out3};
     for (dev_buf *b : bufs) if (b->p) (void)hipFree(b->p);
     for (int i = 0; i < 6; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+    for (int i = 0; i < 6; ++i) if (c->ev2[i]) (void)hipEventDestroy(c->ev2[i]);
+    if (c->stream2) { (void)hipStreamSynchronize(c->stream2); (void)hipStreamDestroy(c->stream2); }
     for (pose_amd_ctx *l : c->lanes) pose_amd_destroy(l);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -261,7 +288,8 @@ int pose_amd_p4pf_batch(pose_amd_ctx *ctx, int count, const double *m2d, const d
     HIPCHK(ctx, hipMemsetAsync(ctx->out1.p, 0, (size_t)count * 80, ctx->stream));
     HIPCHK(ctx, hipMemsetAsync(ctx->out2.p, 0, (size_t)count * 720, ctx->stream));
     HIPCHK(ctx, hipMemsetAsync(ctx->out3.p, 0, (size_t)count * 240, ctx->stream));
-    if ((rc = launch_p4pf(ctx, (uint32_t)count, nullptr, (const double *)ctx->in0.p, (const double *)ctx->in1.p, nullptr, nullptr,
+    ctx->side_used = false;
+    if ((rc = launch_p4pf(ctx, main_io(ctx), (uint32_t)count, nullptr, (const double *)ctx->in0.p, (const double *)ctx->in1.p, nullptr, nullptr,
                           (int *)ctx->out0.p, (double *)ctx->out1.p, (double *)ctx->out2.p, (double *)ctx->out3.p)))
         return rc;
     if ((rc = download(ctx, nsol, ctx->out0.p, (size_t)count * 4))) return rc;
@@ -367,7 +395,20 @@ static bool use_mfma_screen(const pose_amd_ctx *ctx, int nslots, bool want_masks
 }
 
 // projf_ready: the float32 pose copies of these slots were already written by the solver kernels
-static int launch_score(pose_amd_ctx *ctx, int nslots, const double *proj_dev, const int *nsol_dev, int maxsol, double eps,
+static int ensure_feat(pose_amd_ctx *ctx, hipStream_t stream)
+{
+    if (ctx->feat_ready) return POSE_AMD_OK;
+    const query_dev q = make_query(ctx);
+    const int ntiles = cdiv(ctx->n, 32);
+    int rc;
+    if ((rc = ensure(ctx, ctx->feat, (size_t)ntiles * MS_TILE_BYTES))) return rc;
+    hipLaunchKernelGGL(k_make_feat, dim3(cdiv(ntiles * 32, 256)), dim3(256), 0, stream, q, ctx->centre, ntiles, (uint4 *)ctx->feat.p);
+    HIPCHK(ctx, hipGetLastError());
+    ctx->feat_ready = true;
+    return POSE_AMD_OK;
+}
+
+static int launch_score(pose_amd_ctx *ctx, const lane_io &io, int nslots, const double *proj_dev, const int *nsol_dev, int maxsol, double eps,
                         int *counts_dev, unsigned long long *mask_dev, int words_per_pose, bool projf_ready = false)
 {
     const query_dev q = make_query(ctx);
@@ -379,18 +420,13 @@ static int launch_score(pose_amd_ctx *ctx, int nslots, const double *proj_dev, c
     if (use_mfma_screen(ctx, nslots, mask_dev != nullptr)) {
         int rc;
         const int ntiles = cdiv(ctx->n, 32);
-        if (!ctx->feat_ready) {
-            if ((rc = ensure(ctx, ctx->feat, (size_t)ntiles * MS_TILE_BYTES))) return rc;
-            hipLaunchKernelGGL(k_make_feat, dim3(cdiv(ntiles * 32, 256)), dim3(256), 0, ctx->stream, q, ctx->centre, ntiles, (uint4 *)ctx->feat.p);
-            HIPCHK(ctx, hipGetLastError());
-            ctx->feat_ready = true;
-        }
-        if ((rc = ensure(ctx, ctx->vlist, (size_t)nslots * 4)) || (rc = ensure(ctx, ctx->vcount, 4))) return rc;
-        HIPCHK(ctx, hipMemsetAsync(ctx->vcount.p, 0, 4, ctx->stream));
-        hipLaunchKernelGGL(k_compact_valid, dim3(cdiv(nslots, MS_COMPACT_SLOTS)), dim3(256), 0, ctx->stream, nslots, nsol_dev, maxsol, (int *)ctx->vlist.p,
-                           (unsigned int *)ctx->vcount.p);
-        hipLaunchKernelGGL(k_score_mfma, dim3(cdiv(nslots, MS_POSES)), dim3(MS_THREADS), 0, ctx->stream, q, ctx->centre, (const uint4 *)ctx->feat.p,
-                           ntiles, proj_dev, (const int *)ctx->vlist.p, (const unsigned int *)ctx->vcount.p, eps, counts_dev);
+        if ((rc = ensure_feat(ctx, io.stream))) return rc;
+        if ((rc = ensure(ctx, *io.vlist, (size_t)nslots * 4)) || (rc = ensure(ctx, *io.vcount, 4))) return rc;
+        HIPCHK(ctx, hipMemsetAsync(io.vcount->p, 0, 4, io.stream));
+        hipLaunchKernelGGL(k_compact_valid, dim3(cdiv(nslots, MS_COMPACT_SLOTS)), dim3(256), 0, io.stream, nslots, nsol_dev, maxsol, (int *)io.vlist->p,
+                           (unsigned int *)io.vcount->p);
+        hipLaunchKernelGGL(k_score_mfma, dim3(cdiv(nslots, MS_POSES)), dim3(MS_THREADS), 0, io.stream, q, ctx->centre, (const uint4 *)ctx->feat.p,
+                           ntiles, proj_dev, (const int *)io.vlist->p, (const unsigned int *)io.vcount->p, eps, counts_dev);
         HIPCHK(ctx, hipGetLastError());
         return POSE_AMD_OK;
     }
@@ -398,23 +434,23 @@ static int launch_score(pose_amd_ctx *ctx, int nslots, const double *proj_dev, c
         if (!projf_ready) {
             int rc;
             if ((rc = ensure(ctx, ctx->projf, (size_t)nslots * 128))) return rc;
-            hipLaunchKernelGGL(k_make_projf, dim3(cdiv(nslots, 256)), dim3(256), 0, ctx->stream, q, nslots, proj_dev, nsol_dev, maxsol, eps,
+            hipLaunchKernelGGL(k_make_projf, dim3(cdiv(nslots, 256)), dim3(256), 0, io.stream, q, nslots, proj_dev, nsol_dev, maxsol, eps,
                                (float *)ctx->projf.p);
         }
         if (mask_dev)
-            hipLaunchKernelGGL((k_score_screen<true>), grid, block, 0, ctx->stream, q, nslots, proj_dev, (const float *)ctx->projf.p,
+            hipLaunchKernelGGL((k_score_screen<true>), grid, block, 0, io.stream, q, nslots, proj_dev, (const float *)ctx->projf.p,
                                nsol_dev, maxsol, eps, counts_dev, mask_dev, words_per_pose, spb);
         else
-            hipLaunchKernelGGL((k_score_screen<false>), grid, block, 0, ctx->stream, q, nslots, proj_dev, (const float *)ctx->projf.p,
+            hipLaunchKernelGGL((k_score_screen<false>), grid, block, 0, io.stream, q, nslots, proj_dev, (const float *)ctx->projf.p,
                                nsol_dev, maxsol, eps, counts_dev, (unsigned long long *)nullptr, 0, spb);
         HIPCHK(ctx, hipGetLastError());
         return POSE_AMD_OK;
     }
     if (mask_dev)
-        hipLaunchKernelGGL((k_score<4, true>), grid, block, 0, ctx->stream, q, nslots, proj_dev, nsol_dev, maxsol, eps, counts_dev,
+        hipLaunchKernelGGL((k_score<4, true>), grid, block, 0, io.stream, q, nslots, proj_dev, nsol_dev, maxsol, eps, counts_dev,
                            mask_dev, words_per_pose, spb);
     else
-        hipLaunchKernelGGL((k_score<4, false>), grid, block, 0, ctx->stream, q, nslots, proj_dev, nsol_dev, maxsol, eps, counts_dev,
+        hipLaunchKernelGGL((k_score<4, false>), grid, block, 0, io.stream, q, nslots, proj_dev, nsol_dev, maxsol, eps, counts_dev,
                            (unsigned long long *)nullptr, 0, spb);
     HIPCHK(ctx, hipGetLastError());
     return POSE_AMD_OK;
@@ -433,7 +469,7 @@ int pose_amd_score_batch(pose_amd_ctx *ctx, int nposes, const double *P, double 
         if ((rc = ensure(ctx, ctx->maskw, (size_t)nposes * wpp * 8))) return rc;
         HIPCHK(ctx, hipMemsetAsync(ctx->maskw.p, 0, (size_t)nposes * wpp * 8, ctx->stream));
     }
-    if ((rc = launch_score(ctx, nposes, (const double *)ctx->in0.p, nullptr, 1, eps, (int *)ctx->out0.p,
+    if ((rc = launch_score(ctx, main_io(ctx), nposes, (const double *)ctx->in0.p, nullptr, 1, eps, (int *)ctx->out0.p,
                            mask_words ? (unsigned long long *)ctx->maskw.p : nullptr, wpp)))
         return rc;
     if ((rc = download(ctx, counts, ctx->out0.p, (size_t)nposes * 4))) return rc;
@@ -554,33 +590,55 @@ static int run_select(pose_amd_ctx *ctx, int limit, int maxsol, unsigned thresh,
     return pose_amd_synchronize(ctx);
 }
 
-// One chunk of hypotheses [h0, h0+hc): minimal solves then scoring of every returned pose.
-static int solve_and_score(pose_amd_ctx *ctx, uint32_t h0, uint32_t hc, int maxsol, double eps)
+// Minimal solves then scoring of every returned pose for the hypotheses [h0, h0+hc) of the
+// current chunk, whose first hypothesis is c0 (pose slots are indexed relative to the chunk).
+static int solve_and_score_on(pose_amd_ctx *ctx, const lane_io &io, uint32_t c0, uint32_t h0, uint32_t hc, int maxsol, double eps)
 {
     const query_dev q = make_query(ctx);
     const uint32_t *smp = (const uint32_t *)ctx->samples.p + (size_t)h0 * 4;
+    const size_t s0 = (size_t)(h0 - c0) * maxsol;          // first pose slot of this range inside the chunk
+    double *proj = (double *)ctx->proj.p + s0 * 12, *pose = (double *)ctx->pose.p + s0 * 13;
+    int *nsol = (int *)ctx->nsol.p + (h0 - c0), *counts = (int *)ctx->counts.p + s0;
     int rc;
-    // the solver kernels also write the float32 pose copies the scoring screen reads
+    // the solver kernels also write the float32 pose copies the packed scoring screen reads
     float *projf = nullptr;
     if (!ctx->score_fp64_only && !use_mfma_screen(ctx, (int)((size_t)hc * maxsol), false)) {
         if ((rc = ensure(ctx, ctx->projf, (size_t)hc * maxsol * 128))) return rc;
         projf = (float *)ctx->projf.p;
     }
-    HIPCHK(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
+    HIPCHK(ctx, hipEventRecord(io.ev[0], io.stream));
     if (ctx->solver == POSE_AMD_SOLVER_P4PF) {
-        if ((rc = launch_p4pf(ctx, hc, smp, nullptr, nullptr, (double *)ctx->proj.p, (double *)ctx->pose.p, (int *)ctx->nsol.p,
-                              nullptr, nullptr, nullptr, projf, eps)))
-            return rc;
+        if ((rc = launch_p4pf(ctx, io, hc, smp, nullptr, nullptr, proj, pose, nsol, nullptr, nullptr, nullptr, projf, eps))) return rc;
     } else {
-        hipLaunchKernelGGL(k_solve_p3p, dim3(cdiv(hc, 64)), dim3(64), 0, ctx->stream, q, hc, smp, (double *)ctx->proj.p,
-                           (double *)ctx->pose.p, (int *)ctx->nsol.p, projf, eps);
+        hipLaunchKernelGGL(k_solve_p3p, dim3(cdiv(hc, 64)), dim3(64), 0, io.stream, q, hc, smp, proj, pose, nsol, projf, eps);
     }
     HIPCHK(ctx, hipGetLastError());
-    HIPCHK(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
-    if ((rc = launch_score(ctx, (int)((size_t)hc * maxsol), (const double *)ctx->proj.p, (const int *)ctx->nsol.p, maxsol, eps,
-                           (int *)ctx->counts.p, nullptr, 0, projf != nullptr)))
-        return rc;
-    HIPCHK(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
+    HIPCHK(ctx, hipEventRecord(io.ev[1], io.stream));
+    if ((rc = launch_score(ctx, io, (int)((size_t)hc * maxsol), proj, nsol, maxsol, eps, counts, nullptr, 0, projf != nullptr))) return rc;
+    HIPCHK(ctx, hipEventRecord(io.ev[2], io.stream));
+    return POSE_AMD_OK;
+}
+
+// One chunk of hypotheses [h0, h0+hc).  A large chunk of a run without early exit is cut in two
+// halves that go to two streams: their kernels stress different pipes and overlap.
+static int solve_and_score(pose_amd_ctx *ctx, uint32_t h0, uint32_t hc, int maxsol, double eps, bool may_split)
+{
+    int rc;
+    const uint32_t ha = ((hc / 2 + 63) / 64) * 64;
+    ctx->side_used = may_split && ctx->overlap && ha < hc && use_mfma_screen(ctx, (int)((size_t)std::min(ha, hc - ha) * maxsol), false);
+    if (!ctx->side_used) return solve_and_score_on(ctx, main_io(ctx), h0, h0, hc, maxsol, eps);
+    if (!ctx->stream2) {
+        HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
+        for (int i = 0; i < 6; ++i) HIPCHK(ctx, hipEventCreate(&ctx->ev2[i]));
+    }
+    // everything both halves read (samples, query, feature image) is complete on the main stream
+    if ((rc = ensure_feat(ctx, ctx->stream))) return rc;
+    HIPCHK(ctx, hipEventRecord(ctx->ev2[3], ctx->stream));
+    HIPCHK(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev2[3], 0));
+    if ((rc = solve_and_score_on(ctx, main_io(ctx), h0, h0, ha, maxsol, eps))) return rc;
+    if ((rc = solve_and_score_on(ctx, side_io(ctx), h0, h0 + ha, hc - ha, maxsol, eps))) return rc;
+    HIPCHK(ctx, hipEventRecord(ctx->ev2[5], ctx->stream2));
+    HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev2[5], 0));
     return POSE_AMD_OK;
 }
 
@@ -639,7 +697,7 @@ int pose_amd_ransac_run(pose_amd_ctx *ctx, const pose_amd_params *prm, pose_amd_
         hc = std::min(next_chunk, H - h0);
         next_chunk = std::min(chunk, next_chunk * 4);
         const size_t nslots = (size_t)hc * maxsol;
-        if ((rc = solve_and_score(ctx, h0, hc, maxsol, prm->eps))) return rc;
+        if ((rc = solve_and_score(ctx, h0, hc, maxsol, prm->eps, !prm->early_exit))) return rc;
         long long chunk_best = -1;       // slot within the chunk that became the kept pose
         uint32_t chunk_steps = hc;
         if (!coverage) {
@@ -698,6 +756,8 @@ int pose_amd_ransac_run(pose_amd_ctx *ctx, const pose_amd_params *prm, pose_amd_
         HIPCHK(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
         HIPCHK(ctx, hipEventSynchronize(ctx->ev[3]));
         float ms;
+        // per-kernel times are sums over the launches (both streams when the chunk was split, in
+        // which case they overlap and add up to more than the chunk's wall time in [3])
         for (int i = 0; i < 3; ++i) { (void)hipEventElapsedTime(&ms, ctx->ev[i], ctx->ev[i + 1]); ctx->last_ms[i] += ms; }
         (void)hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[3]); ctx->last_ms[3] += ms;
         if (ctx->solver == POSE_AMD_SOLVER_P4PF) {
@@ -705,6 +765,14 @@ int pose_amd_ransac_run(pose_amd_ctx *ctx, const pose_amd_params *prm, pose_amd_
             (void)hipEventElapsedTime(&ms, ctx->ev[4], ctx->ev[1]); ctx->last_ms[5] += ms;
         }
         ctx->last_ms[6] += 1.0f;
+        if (ctx->side_used) {
+            for (int i = 0; i < 2; ++i) { (void)hipEventElapsedTime(&ms, ctx->ev2[i], ctx->ev2[i + 1]); ctx->last_ms[i] += ms; }
+            if (ctx->solver == POSE_AMD_SOLVER_P4PF) {
+                (void)hipEventElapsedTime(&ms, ctx->ev2[0], ctx->ev2[4]); ctx->last_ms[4] += ms;
+                (void)hipEventElapsedTime(&ms, ctx->ev2[4], ctx->ev2[1]); ctx->last_ms[5] += ms;
+            }
+            ctx->last_ms[6] += 1.0f;
+        }
         steps += chunk_steps;
         if (chunk_best >= 0) {
             best_slot = (long long)h0 * maxsol + chunk_best;
