@@ -360,12 +360,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                               double *__restrict__ proj, double *__restrict__ pose, int *__restrict__ nsol, double *__restrict__ fo,
                               double *__restrict__ Ro, double *__restrict__ to, float *__restrict__ projf, double eps)
 {
-    const size_t h = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (h >= hyp_count) return;
-    int n = status[h];
-    p4pf_problem pb;
+    // Accepted roots wait here for the pose recovery: hypotheses have 0..10 of them (1.6 on
+    // average), so recovering "root s of my hypothesis" in lock step would keep a third of the
+    // lanes busy.  Instead the roots of the whole wave are queued and recovered 64 at a time, one
+    // per lane, by whichever lane gets them (it re-derives the normalised problem of the root's
+    // hypothesis from the sample, which is cheap next to the rigid fit).
+    __shared__ p4pf_root s_root[128];
+    __shared__ unsigned short s_meta[128];               // source lane | root index << 8
+    const int lane = threadIdx.x;
+    const size_t h0 = (size_t)blockIdx.x * blockDim.x, h = h0 + lane;
+    const bool live = h < hyp_count;
+    int n = live ? status[h] : -1;
     p4pf_root roots[10];
     if (n == 0) {
+        p4pf_problem pb;
         double m2d[8], M3D[12];
         p4pf_fetch(q, samples, m2d_in, M3D_in, h, m2d, M3D);
         p4pf_normalise(m2d, M3D, pb);
@@ -375,18 +383,55 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         n = p4pf_reduce_tail(tl, a);
         if (n == 0) n = p4pf_roots_sextic(a, pb, roots);
     }
-    nsol[h] = n;
-    for (int s = 0; s < n; ++s) {
-        double f, R[9], t[3];
-        p4pf_pose_from_root(pb, roots[s], f, R, t);
-        if (proj) {
-            store_p4pf_solution(proj, pose, h * P4PF_MAXSOL + s, f, R, t, projf, q, eps);
-        } else {
-            fo[10 * h + s] = f;
-            for (int r = 0; r < 9; ++r) Ro[90 * h + 9 * s + r] = R[r];
-            for (int r = 0; r < 3; ++r) to[30 * h + 3 * s + r] = t[r];
+    if (live) nsol[h] = n;
+
+    auto recover = [&](int count) {                      // queue entries [0, count), count <= 64
+        if (lane < count) {
+            const p4pf_root rt = s_root[lane];
+            const int src = s_meta[lane] & 0xff, s = s_meta[lane] >> 8;
+            const size_t hh = h0 + src;
+            p4pf_problem pb;
+            double m2d[8], M3D[12];
+            p4pf_fetch(q, samples, m2d_in, M3D_in, hh, m2d, M3D);
+            p4pf_normalise(m2d, M3D, pb);
+            double f, R[9], t[3];
+            p4pf_pose_from_root(pb, rt, f, R, t);
+            if (proj) {
+                store_p4pf_solution(proj, pose, hh * P4PF_MAXSOL + s, f, R, t, projf, q, eps);
+            } else {
+                fo[10 * hh + s] = f;
+                for (int r = 0; r < 9; ++r) Ro[90 * hh + 9 * s + r] = R[r];
+                for (int r = 0; r < 3; ++r) to[30 * hh + 3 * s + r] = t[r];
+            }
+        }
+    };
+    int nmax = n > 0 ? n : 0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) nmax = max(nmax, __shfl_xor(nmax, o));
+    int qn = 0;                                          // wave-uniform queue length
+    for (int r = 0; r < nmax; ++r) {
+        const bool has = r < n;
+        const unsigned long long m = __ballot(has);
+        if (has) {
+            const int pos = qn + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+            s_root[pos] = roots[r];
+            s_meta[pos] = (unsigned short)(lane | (r << 8));
+        }
+        qn += __popcll(m);
+        __builtin_amdgcn_wave_barrier();
+        if (qn >= 64) {
+            recover(64);
+            __builtin_amdgcn_wave_barrier();
+            const bool mv = lane < qn - 64;
+            p4pf_root keep = s_root[mv ? 64 + lane : 0];
+            const unsigned short km = s_meta[mv ? 64 + lane : 0];
+            __builtin_amdgcn_wave_barrier();
+            if (mv) { s_root[lane] = keep; s_meta[lane] = km; }
+            qn -= 64;
+            __builtin_amdgcn_wave_barrier();
         }
     }
+    recover(qn);
 }
 
 // Raw batched solver kernels for the parity entry points (inputs straight from the caller).
