@@ -378,7 +378,7 @@ PA_HD int p4pf_roots_sextic(const double (&a)[50], const p4pf_problem &pb, p4pf_
         double L = lam[t];
         double S[5][5], y[4];
         // Newton on det P(L).  The eigenvector of the last evaluation is kept once the step is
-        // below 1e-12 relative (its error is of the order of that step); a step above 5 % means
+        // below 1e-13 relative (its error is of the order of that step); a step above 5 % means
         // the start was not in the basin of a root of det P and L is left where it is.
         bool resolve = true;
         for (int it = 0; it < 5; ++it) {
@@ -389,7 +389,7 @@ PA_HD int p4pf_roots_sextic(const double (&a)[50], const p4pf_problem &pb, p4pf_
             const double scale = fmax(1.0, fabs(L));
             if (!(d == d) || fabs(d) > 0.05 * scale) { resolve = false; break; }
             L -= d;
-            if (fabs(d) <= 1e-12 * scale) { resolve = false; break; }
+            if (fabs(d) <= 1e-13 * scale) { resolve = false; break; }
         }
         if (resolve) {
             p4pf_build_system(a, L, S);
