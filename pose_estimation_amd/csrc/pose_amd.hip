@@ -424,7 +424,7 @@ static int launch_score(pose_amd_ctx *ctx, const lane_io &io, int nslots, const 
         if ((rc = ensure(ctx, *io.vlist, (size_t)nslots * 4)) || (rc = ensure(ctx, *io.vcount, 4))) return rc;
         HIPCHK(ctx, hipMemsetAsync(io.vcount->p, 0, 4, io.stream));
         hipLaunchKernelGGL(k_compact_valid, dim3(cdiv(nslots, MS_COMPACT_SLOTS)), dim3(256), 0, io.stream, nslots, nsol_dev, maxsol, (int *)io.vlist->p,
-                           (unsigned int *)io.vcount->p);
+                           (unsigned int *)io.vcount->p, counts_dev);
         hipLaunchKernelGGL(k_score_mfma, dim3(cdiv(nslots, MS_POSES)), dim3(MS_THREADS), 0, io.stream, q, ctx->centre, (const uint4 *)ctx->feat.p,
                            ntiles, proj_dev, (const int *)io.vlist->p, (const unsigned int *)io.vcount->p, eps, counts_dev);
         HIPCHK(ctx, hipGetLastError());

@@ -102,9 +102,10 @@ __global__ void k_make_feat(query_dev q, query_centre qc, int ntiles, uint4 *__r
 
 // Dense list of the valid pose slots (slot % maxsol < nsol[slot / maxsol]); order unspecified.
 // A block of 256 threads handles MS_COMPACT_SLOTS consecutive slots with one atomic reservation.
+// counts[] of the slots that are not valid is set to 0 (the scoring kernel writes the others).
 constexpr int MS_COMPACT_SLOTS = 4096;
 __global__ __launch_bounds__(256) void k_compact_valid(int nslots, const int *__restrict__ nsol, int maxsol, int *__restrict__ vlist,
-                                                       unsigned int *__restrict__ counter)
+                                                       unsigned int *__restrict__ counter, int *__restrict__ counts)
 {
     __shared__ int s_n[4];
     __shared__ unsigned s_base;
@@ -115,6 +116,7 @@ __global__ __launch_bounds__(256) void k_compact_valid(int nslots, const int *__
     for (int k = 0; k < MS_COMPACT_SLOTS / 256; ++k) {
         const int slot = slot0 + k;
         if (slot < nslots && (!nsol || (slot % maxsol) < nsol[slot / maxsol])) valid |= 1u << k;
+        else if (slot < nslots) counts[slot] = 0;
     }
     const int mine = __popc(valid);
     // exclusive prefix of `mine` inside the wave
