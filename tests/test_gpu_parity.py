@@ -501,6 +501,30 @@ def test_score_matrix_core_screen_equals_float64_kernel(ctx):
                 assert c0.max() > 0.1 * n and c0[5] == 0 and c0[6] == 0 and c0[10] == 0
 
 
+def test_two_stream_split_gives_the_same_run(ctx):
+    """POSE_AMD_OVERLAP=1 cuts a large fixed-budget chunk in two halves on two streams; per-pose
+    solutions, counts and the kept pose must not change."""
+    from pose_estimation_amd import Context
+    os.environ["POSE_AMD_OVERLAP"] = "1"
+    try:
+        split_ctx = Context(0)
+    finally:
+        del os.environ["POSE_AMD_OVERLAP"]
+    with split_ctx:
+        for known, n, H in ((False, 3000, 1 << 18), (True, 1500, 1 << 18), (False, 700, (1 << 18) + 77)):
+            q = synth.make_query(n, 0.15, 31 + n, known_focal=known)
+            res = []
+            for c in (ctx, split_ctx):
+                upload(c, q)
+                c.sample(SAMPLE_BASIC, 55, 3, 0, H, export=False)
+                res.append(c.ransac_run(SELECT_INLIERS, 0.5, early_exit=False, hyp_count=H, want_per_hyp=True))
+            a, b = res
+            assert np.array_equal(a["nsol"], b["nsol"]) and np.array_equal(a["counts"], b["counts"])
+            for k in ("best_hyp", "best_sol", "inliers", "steps", "poses_scored"):
+                assert a[k] == b[k], k
+            assert np.array_equal(a["C"], b["C"]) and np.array_equal(a["Rc"], b["Rc"]) and a["focal"] == b["focal"]
+
+
 def test_ransac_large_query_config5_shape(ctx):
     """BASELINE config 5 in miniature: 100 000 matches, 1 % inliers, a hypothesis range split in
     two halves whose packed keys are max-reduced (what the ranks do) equals the whole range."""

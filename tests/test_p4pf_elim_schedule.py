@@ -22,6 +22,30 @@ def test_schedule_shape():
     assert done == list(range(78))                     # every left-hand column is eliminated once
 
 
+def test_stage1_order_is_valid_and_in_lane_steps_are_co_located():
+    """A stage-1 pivot row must never have been a target of an earlier step (its entries are read
+    as plain coefficients), whatever order the pivots are taken in; the stage-2 steps marked
+    in-lane have exactly two candidate rows, in the two slots of one lane, which no other in-lane
+    step shares; positions are a permutation of 0..28."""
+    s = G.build_schedule()
+    touched = set()
+    for st in s["steps"]:
+        assert st["row"] not in touched
+        touched |= set(st["targets"])
+    pos = s["lane_of"]
+    assert sorted(pos.values()) == list(range(29))
+    used = set()
+    in_lane = [st for st in s["stage2"] if st.get("in_lane")]
+    assert len(in_lane) >= 2
+    for st in in_lane:
+        a, b = (pos[r] for r in st["cand"])
+        assert len(st["cand"]) == 2 and abs(a - b) == 16 and not ({a, b} & used)
+        used |= {a, b}
+    # in-lane steps come first: later steps may involve the rows they retire
+    flags = [bool(st.get("in_lane")) for st in s["stage2"]]
+    assert flags == sorted(flags, reverse=True)
+
+
 def test_schedule_reproduces_action_matrix_rows():
     s = G.build_schedule()
     m, M = synth.random_p4pf_problems(60, seed=9, contaminate=(0, 1), noise=0.2)
