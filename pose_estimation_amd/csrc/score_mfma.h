@@ -110,11 +110,11 @@ __global__ __launch_bounds__(256) void k_compact_valid(int nslots, const int *__
     __shared__ int s_n[4];
     __shared__ unsigned s_base;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int slot0 = blockIdx.x * MS_COMPACT_SLOTS + threadIdx.x * (MS_COMPACT_SLOTS / 256);
-    unsigned valid = 0;                                  // bit k: slot0 + k is valid
+    const int slot0 = blockIdx.x * MS_COMPACT_SLOTS + threadIdx.x;     // the thread looks at slot0 + 256 k (coalesced)
+    unsigned valid = 0;                                  // bit k: slot0 + 256 k is valid
 #pragma unroll
     for (int k = 0; k < MS_COMPACT_SLOTS / 256; ++k) {
-        const int slot = slot0 + k;
+        const int slot = slot0 + 256 * k;
         if (slot < nslots && (!nsol || (slot % maxsol) < nsol[slot / maxsol])) valid |= 1u << k;
         else if (slot < nslots) counts[slot] = 0;
     }
@@ -134,7 +134,7 @@ __global__ __launch_bounds__(256) void k_compact_valid(int nslots, const int *__
     for (int w = 0; w < 4; ++w) if (w < wave) off += s_n[w];
 #pragma unroll
     for (int k = 0; k < MS_COMPACT_SLOTS / 256; ++k)
-        if ((valid >> k) & 1u) vlist[off++] = slot0 + k;
+        if ((valid >> k) & 1u) vlist[off++] = slot0 + 256 * k;
 }
 
 struct ms_pose_ops {
