@@ -854,6 +854,23 @@ __global__ __launch_bounds__(256) void k_select(int limit, const int *__restrict
     }
 }
 
+// After k_select: copies the three result words and the pose / projection matrix of the best
+// slot behind them (sel[3..5] = results, sel[6..18] = pose, sel[19..30] = projection matrix), so
+// that the host fetches everything with one copy, and re-arms sel[0..2] for the next selection.
+__global__ void k_gather_best(unsigned long long *__restrict__ sel, const double *__restrict__ pose, const double *__restrict__ proj)
+{
+    const int t = threadIdx.x;
+    const unsigned long long key = sel[0], first = sel[1], nvalid = sel[2];
+    __syncthreads();
+    double *out = reinterpret_cast<double *>(sel);
+    if (nvalid != 0ull) {
+        const size_t slot = (size_t)(0xFFFFFFFFu - (unsigned int)(key & 0xFFFFFFFFull));
+        if (t < 13) out[6 + t] = pose[slot * 13 + t];
+        if (t < 12) out[19 + t] = proj[slot * 12 + t];
+    }
+    if (t == 0) { sel[3] = key; sel[4] = first; sel[5] = nvalid; sel[0] = 0ull; sel[1] = ~0ull; sel[2] = 0ull; }
+}
+
 } // namespace pose_amd
 
 #include "score_mfma.h"

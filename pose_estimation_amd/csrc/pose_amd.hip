@@ -51,6 +51,13 @@ struct pose_amd_ctx {
     hipEvent_t ev2[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // [3] = fork, [5] = join
     dev_buf arows2, pstatus2, vlist2, vcount2;
     bool side_used = false;        // the last solve_and_score call used the second stream
+    bool lazy_sync = false;        // worker contexts of the batch entry point: no host synchronisation where only the API contract asks for it
+    dev_buf qpack;                 // the query's five (six) arrays in one allocation; kx .. lindex point into it
+    void *qstage = nullptr;        // pinned staging copy of the same, so that a query is one host-to-device copy
+    size_t qstage_cap = 0;
+    bool sel_armed = false;        // sel[0..2] hold the initial values of a selection
+    bool timing = true;            // record per-kernel timing events (off for the batch entry point's worker contexts:
+                                   // every event is one more command for the GPU's command processor)
     // batch entry point: child contexts (one stream each) and their pinned result words
     std::vector<pose_amd_ctx *> lanes;
     // hypotheses
@@ -152,7 +159,7 @@ static int launch_p4pf(pose_amd_ctx *ctx, const lane_io &io, uint32_t count, con
     hipLaunchKernelGGL(k_p4pf_elim, dim3(ctx->side_used ? std::min(nbatch, slots) : nbatch), dim3(64), 0, io.stream, q, count, samples, m2d, M3D,
                        (double *)io.arows->p, (int *)io.pstatus->p, batch);
     HIPCHK(ctx, hipGetLastError());
-    HIPCHK(ctx, hipEventRecord(io.ev[4], io.stream));     // end of the elimination kernel, for the per-kernel timing
+    if (ctx->timing) HIPCHK(ctx, hipEventRecord(io.ev[4], io.stream));     // end of the elimination kernel, for the per-kernel timing
     hipLaunchKernelGGL(k_p4pf_finish, dim3(cdiv(count, 64)), dim3(64), 0, io.stream, q, count, samples, m2d, M3D,
                        (const double *)io.arows->p, (const int *)io.pstatus->p, proj, pose, nsol, fo, Ro, to, projf, eps);
     HIPCHK(ctx, hipGetLastError());
@@ -208,10 +215,11 @@ void pose_amd_destroy(pose_amd_ctx *c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    dev_buf *bufs[] = {&c->kx, &c->ky, &c->X, &c->Y, &c->Z, &c->lindex, &c->cam_off, &c->cam_ids, &c->gain, &c->samples,
+    dev_buf *bufs[] = {&c->qpack, &c->cam_off, &c->cam_ids, &c->gain, &c->samples,
                        &c->sample_status, &c->proj, &c->pose, &c->nsol, &c->counts, &c->sel, &c->bitmaps, &c->areas,
                        &c->maskw, &c->arows, &c->pstatus, &c->projf, &c->feat, &c->vlist, &c->vcount, &c->arows2, &c->pstatus2, &c->vlist2, &c->vcount2, &c->in0, &c->in1, &c->in2, &c->out0, &c->out1, &c->out2, &c->out3};
     for (dev_buf *b : bufs) if (b->p) (void)hipFree(b->p);
+    if (c->qstage) (void)hipHostFree(c->qstage);
     for (int i = 0; i < 6; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
     for (int i = 0; i < 6; ++i) if (c->ev2[i]) (void)hipEventDestroy(c->ev2[i]);
     if (c->stream2) { (void)hipStreamSynchronize(c->stream2); (void)hipStreamDestroy(c->stream2); }
@@ -308,12 +316,24 @@ int pose_amd_set_query(pose_amd_ctx *ctx, int n, const float *kx, const float *k
     if (!(focal >= 0.0)) return fail(ctx, POSE_AMD_EINVAL, "set_query: focal must be >= 0 (0 selects P4Pf)");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     int rc;
-    const size_t b = (size_t)n * 4;
-    if ((rc = upload(ctx, ctx->kx, kx, b)) || (rc = upload(ctx, ctx->ky, ky, b)) || (rc = upload(ctx, ctx->X, X, b)) ||
-        (rc = upload(ctx, ctx->Y, Y, b)) || (rc = upload(ctx, ctx->Z, Z, b)))
-        return rc;
+    // one staging copy, one host-to-device copy: every separate copy is a command of its own for the GPU
+    const size_t b = (((size_t)n * 4) + 255) / 256 * 256, total = b * 6;
+    if ((rc = ensure(ctx, ctx->qpack, total))) return rc;
+    if (total > ctx->qstage_cap) {
+        if (ctx->qstage) { HIPCHK(ctx, hipHostFree(ctx->qstage)); ctx->qstage = nullptr; ctx->qstage_cap = 0; }
+        HIPCHK(ctx, hipHostMalloc(&ctx->qstage, total + total / 8, hipHostMallocDefault));
+        ctx->qstage_cap = total + total / 8;
+    }
     ctx->has_lindex = lindex != nullptr;
-    if (lindex && (rc = upload(ctx, ctx->lindex, lindex, b))) return rc;
+    const void *src[6] = {kx, ky, X, Y, Z, lindex};
+    dev_buf *dst[6] = {&ctx->kx, &ctx->ky, &ctx->X, &ctx->Y, &ctx->Z, &ctx->lindex};
+    const int narr = lindex ? 6 : 5;
+    for (int i = 0; i < narr; ++i) {
+        if (n) memcpy((char *)ctx->qstage + b * i, src[i], (size_t)n * 4);
+        dst[i]->p = (char *)ctx->qpack.p + b * i;          // views into qpack, not owned
+        dst[i]->cap = 0;
+    }
+    if (n) HIPCHK(ctx, hipMemcpyAsync(ctx->qpack.p, ctx->qstage, b * narr, hipMemcpyHostToDevice, ctx->stream));
     ctx->n = n; ctx->width = width; ctx->height = height; ctx->focal = focal;
     // magnitudes for the error bound of the float32 screen; a NaN makes the bound NaN, which
     // sends every pair to the float64 test
@@ -341,7 +361,9 @@ int pose_amd_set_query(pose_amd_ctx *ctx, int n, const float *kx, const float *k
     ctx->hyp_count = 0;
     ctx->have_best = false;
     ctx->area_all = -1;
-    return pose_amd_synchronize(ctx);
+    // the staging buffer is reused by the next call: worker contexts of the batch entry point get
+    // there only after the run of this query has been synchronised
+    return ctx->lazy_sync ? POSE_AMD_OK : pose_amd_synchronize(ctx);
 }
 
 int pose_amd_set_camsets(pose_amd_ctx *ctx, const uint32_t *cam_off, const uint32_t *cam_ids)
@@ -552,7 +574,7 @@ int pose_amd_sample(pose_amd_ctx *ctx, int sample_mode, uint64_t seed, uint32_t 
     }
     HIPCHK(ctx, hipGetLastError());
     if (samples_out && (rc = download(ctx, samples_out, ctx->samples.p, (size_t)hyp_count * 16))) return rc;
-    if ((rc = pose_amd_synchronize(ctx))) return rc;
+    if ((samples_out || !ctx->lazy_sync) && (rc = pose_amd_synchronize(ctx))) return rc;
     ctx->hyp_count = hyp_count;
     return POSE_AMD_OK;
 }
@@ -574,20 +596,32 @@ int pose_amd_set_samples(pose_amd_ctx *ctx, const uint32_t *samples, uint32_t hy
 }
 
 // ---- RANSAC ---------------------------------------------------------------------------------------
-static int run_select(pose_amd_ctx *ctx, int limit, int maxsol, unsigned thresh, unsigned long long out[3])
+// Selection over the first `limit` slots of the chunk.  out[0..2] = best key, first slot reaching
+// `thresh`, valid slots; best[0..12] = pose record and best[13..24] = projection matrix of the best
+// slot (unchanged when there is no valid slot).  One download for everything.
+static int run_select(pose_amd_ctx *ctx, int limit, int maxsol, unsigned thresh, unsigned long long out[3], double best[25])
 {
     int rc;
-    if ((rc = ensure(ctx, ctx->sel, 24))) return rc;
-    const unsigned long long init[3] = {0ull, ~0ull, 0ull};
-    HIPCHK(ctx, hipMemcpyAsync(ctx->sel.p, init, 24, hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = ensure(ctx, ctx->sel, 31 * 8))) return rc;
+    if (!ctx->sel_armed) {
+        const unsigned long long init[3] = {0ull, ~0ull, 0ull};
+        HIPCHK(ctx, hipMemcpyAsync(ctx->sel.p, init, 24, hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));      // init is a stack array
+        ctx->sel_armed = true;                               // k_gather_best re-arms it after every selection
+    }
     int blocks = cdiv(limit, 256);
     if (blocks > 1024) blocks = 1024;
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(k_select, dim3(blocks), dim3(256), 0, ctx->stream, limit, (const int *)ctx->counts.p, (const int *)ctx->nsol.p,
                        maxsol, thresh, (unsigned long long *)ctx->sel.p);
+    hipLaunchKernelGGL(k_gather_best, dim3(1), dim3(64), 0, ctx->stream, (unsigned long long *)ctx->sel.p, (const double *)ctx->pose.p,
+                       (const double *)ctx->proj.p);
     HIPCHK(ctx, hipGetLastError());
-    if ((rc = download(ctx, out, ctx->sel.p, 24))) return rc;
-    return pose_amd_synchronize(ctx);
+    unsigned long long host[28];
+    if ((rc = download(ctx, host, (const char *)ctx->sel.p + 24, 28 * 8)) || (rc = pose_amd_synchronize(ctx))) return rc;
+    memcpy(out, host, 24);
+    if (host[2] != 0ull) memcpy(best, host + 3, 25 * 8);
+    return POSE_AMD_OK;
 }
 
 // Minimal solves then scoring of every returned pose for the hypotheses [h0, h0+hc) of the
@@ -606,16 +640,16 @@ static int solve_and_score_on(pose_amd_ctx *ctx, const lane_io &io, uint32_t c0,
         if ((rc = ensure(ctx, ctx->projf, (size_t)hc * maxsol * 128))) return rc;
         projf = (float *)ctx->projf.p;
     }
-    HIPCHK(ctx, hipEventRecord(io.ev[0], io.stream));
+    if (ctx->timing) HIPCHK(ctx, hipEventRecord(io.ev[0], io.stream));
     if (ctx->solver == POSE_AMD_SOLVER_P4PF) {
         if ((rc = launch_p4pf(ctx, io, hc, smp, nullptr, nullptr, proj, pose, nsol, nullptr, nullptr, nullptr, projf, eps))) return rc;
     } else {
         hipLaunchKernelGGL(k_solve_p3p, dim3(cdiv(hc, 64)), dim3(64), 0, io.stream, q, hc, smp, proj, pose, nsol, projf, eps);
     }
     HIPCHK(ctx, hipGetLastError());
-    HIPCHK(ctx, hipEventRecord(io.ev[1], io.stream));
+    if (ctx->timing) HIPCHK(ctx, hipEventRecord(io.ev[1], io.stream));
     if ((rc = launch_score(ctx, io, (int)((size_t)hc * maxsol), proj, nsol, maxsol, eps, counts, nullptr, 0, projf != nullptr))) return rc;
-    HIPCHK(ctx, hipEventRecord(io.ev[2], io.stream));
+    if (ctx->timing) HIPCHK(ctx, hipEventRecord(io.ev[2], io.stream));
     return POSE_AMD_OK;
 }
 
@@ -699,19 +733,21 @@ int pose_amd_ransac_run(pose_amd_ctx *ctx, const pose_amd_params *prm, pose_amd_
         const size_t nslots = (size_t)hc * maxsol;
         if ((rc = solve_and_score(ctx, h0, hc, maxsol, prm->eps, !prm->early_exit))) return rc;
         long long chunk_best = -1;       // slot within the chunk that became the kept pose
+        bool have_gathered = false;      // its pose and projection matrix came with the selection's download
+        double gathered[25];
         uint32_t chunk_steps = hc;
         if (!coverage) {
             unsigned long long out[3];
-            if ((rc = run_select(ctx, (int)nslots, maxsol, prm->early_exit ? thresh_u : 0xFFFFFFFFu, out))) return rc;
+            if ((rc = run_select(ctx, (int)nslots, maxsol, prm->early_exit ? thresh_u : 0xFFFFFFFFu, out, gathered))) return rc;
             if (prm->early_exit && out[1] != ~0ull) {
                 chunk_steps = (uint32_t)(out[1] / maxsol) + 1;
                 done = true;
-                if (chunk_steps < hc && (rc = run_select(ctx, (int)((size_t)chunk_steps * maxsol), maxsol, 0xFFFFFFFFu, out))) return rc;
+                if (chunk_steps < hc && (rc = run_select(ctx, (int)((size_t)chunk_steps * maxsol), maxsol, 0xFFFFFFFFu, out, gathered))) return rc;
             }
             poses_scored += out[2];
             const uint32_t c = (uint32_t)(out[0] >> 32);
             // strictly better than everything before it; counts start from hypoquality 0 (basic.cpp:119,214)
-            if (c > best_count) { best_count = c; chunk_best = (long long)(0xFFFFFFFFu - (uint32_t)(out[0] & 0xFFFFFFFFu)); }
+            if (c > best_count) { best_count = c; chunk_best = (long long)(0xFFFFFFFFu - (uint32_t)(out[0] & 0xFFFFFFFFu)); have_gathered = true; }
         } else {
             // Coverage quality q = A_f / A_g (query_processor.cpp:171-174).  A_g is fixed for the
             // query, so q1 > q2 <=> A_f1 > A_f2, and A_f <= count * box prunes poses that cannot win.
@@ -753,28 +789,34 @@ int pose_amd_ransac_run(pose_amd_ctx *ctx, const pose_amd_params *prm, pose_amd_
                 BATCH = std::min(4096, BATCH * 4);
             }
         }
-        HIPCHK(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
-        HIPCHK(ctx, hipEventSynchronize(ctx->ev[3]));
-        float ms;
-        // per-kernel times are sums over the launches (both streams when the chunk was split, in
-        // which case they overlap and add up to more than the chunk's wall time in [3])
-        for (int i = 0; i < 3; ++i) { (void)hipEventElapsedTime(&ms, ctx->ev[i], ctx->ev[i + 1]); ctx->last_ms[i] += ms; }
-        (void)hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[3]); ctx->last_ms[3] += ms;
-        if (ctx->solver == POSE_AMD_SOLVER_P4PF) {
-            (void)hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[4]); ctx->last_ms[4] += ms;
-            (void)hipEventElapsedTime(&ms, ctx->ev[4], ctx->ev[1]); ctx->last_ms[5] += ms;
-        }
-        ctx->last_ms[6] += 1.0f;
-        if (ctx->side_used) {
-            for (int i = 0; i < 2; ++i) { (void)hipEventElapsedTime(&ms, ctx->ev2[i], ctx->ev2[i + 1]); ctx->last_ms[i] += ms; }
+        if (ctx->timing) {
+            HIPCHK(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
+            HIPCHK(ctx, hipEventSynchronize(ctx->ev[3]));
+            float ms;
+            // per-kernel times are sums over the launches (both streams when the chunk was split, in
+            // which case they overlap and add up to more than the chunk's wall time in [3])
+            for (int i = 0; i < 3; ++i) { (void)hipEventElapsedTime(&ms, ctx->ev[i], ctx->ev[i + 1]); ctx->last_ms[i] += ms; }
+            (void)hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[3]); ctx->last_ms[3] += ms;
             if (ctx->solver == POSE_AMD_SOLVER_P4PF) {
-                (void)hipEventElapsedTime(&ms, ctx->ev2[0], ctx->ev2[4]); ctx->last_ms[4] += ms;
-                (void)hipEventElapsedTime(&ms, ctx->ev2[4], ctx->ev2[1]); ctx->last_ms[5] += ms;
+                (void)hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[4]); ctx->last_ms[4] += ms;
+                (void)hipEventElapsedTime(&ms, ctx->ev[4], ctx->ev[1]); ctx->last_ms[5] += ms;
             }
             ctx->last_ms[6] += 1.0f;
+            if (ctx->side_used) {
+                for (int i = 0; i < 2; ++i) { (void)hipEventElapsedTime(&ms, ctx->ev2[i], ctx->ev2[i + 1]); ctx->last_ms[i] += ms; }
+                if (ctx->solver == POSE_AMD_SOLVER_P4PF) {
+                    (void)hipEventElapsedTime(&ms, ctx->ev2[0], ctx->ev2[4]); ctx->last_ms[4] += ms;
+                    (void)hipEventElapsedTime(&ms, ctx->ev2[4], ctx->ev2[1]); ctx->last_ms[5] += ms;
+                }
+                ctx->last_ms[6] += 1.0f;
+            }
         }
         steps += chunk_steps;
-        if (chunk_best >= 0) {
+        if (chunk_best >= 0 && have_gathered) {
+            best_slot = (long long)h0 * maxsol + chunk_best;
+            memcpy(best_pose, gathered, 104);
+            memcpy(ctx->best_proj, gathered + 13, 96);
+        } else if (chunk_best >= 0) {
             best_slot = (long long)h0 * maxsol + chunk_best;
             if ((rc = download(ctx, best_pose, (const char *)ctx->pose.p + (size_t)chunk_best * 104, 104)) ||
                 (rc = download(ctx, ctx->best_proj, (const char *)ctx->proj.p + (size_t)chunk_best * 96, 96)) ||
@@ -821,6 +863,8 @@ int pose_amd_ransac_batch(pose_amd_ctx *ctx, int nq, const pose_amd_query *queri
     while ((int)ctx->lanes.size() < nl) {
         pose_amd_ctx *l = nullptr;
         if (pose_amd_create(ctx->device, &l) != POSE_AMD_OK) return fail(ctx, POSE_AMD_EHIP, "ransac_batch: cannot create an internal stream");
+        l->timing = false;
+        l->lazy_sync = true;
         ctx->lanes.push_back(l);
     }
     std::atomic<int> next(0), status(POSE_AMD_OK);
