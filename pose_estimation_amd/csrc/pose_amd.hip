@@ -407,11 +407,11 @@ int pose_amd_compute_matrices_batch(pose_amd_ctx *ctx, int count, const double *
     return pose_amd_synchronize(ctx);
 }
 
-// The matrix-core screen counts only (no masks) and pays off for large launches; small ones
+// The matrix-core screen counts only (no masks); launches of a few thousand poses or fewer
 // (early-exit chunks, single poses) keep the packed-float32 kernel, whose blocks adapt to them.
 static bool use_mfma_screen(const pose_amd_ctx *ctx, int nslots, bool want_masks)
 {
-    static const int min_slots = getenv("POSE_AMD_MFMA_MIN_SLOTS") ? atoi(getenv("POSE_AMD_MFMA_MIN_SLOTS")) : 131072;
+    static const int min_slots = getenv("POSE_AMD_MFMA_MIN_SLOTS") ? atoi(getenv("POSE_AMD_MFMA_MIN_SLOTS")) : 8192;
     return ctx->score_mfma && !ctx->score_fp64_only && !want_masks && nslots >= min_slots && ctx->n <= MS_MAX_N - 32 &&
            ctx->centre.xmaxc == ctx->centre.xmaxc && ctx->umax == ctx->umax;
 }
@@ -445,10 +445,16 @@ static int launch_score(pose_amd_ctx *ctx, const lane_io &io, int nslots, const 
         if ((rc = ensure_feat(ctx, io.stream))) return rc;
         if ((rc = ensure(ctx, *io.vlist, (size_t)nslots * 4)) || (rc = ensure(ctx, *io.vcount, 4))) return rc;
         HIPCHK(ctx, hipMemsetAsync(io.vcount->p, 0, 4, io.stream));
+        // a launch with few poses is also cut along the correspondences, so that it still has a
+        // thousand blocks or so; their counts are then added up with atomics
+        const int pose_batches = cdiv(nslots, MS_POSES), nchunks = cdiv(ntiles, MS_CHUNK_TILES);
+        int gy = pose_batches >= 1024 ? 1 : std::min(nchunks, std::max(1, 1024 / pose_batches));
+        const int tpb = cdiv(nchunks, gy) * MS_CHUNK_TILES;
+        gy = cdiv(ntiles, tpb);
         hipLaunchKernelGGL(k_compact_valid, dim3(cdiv(nslots, MS_COMPACT_SLOTS)), dim3(256), 0, io.stream, nslots, nsol_dev, maxsol, (int *)io.vlist->p,
-                           (unsigned int *)io.vcount->p, counts_dev);
-        hipLaunchKernelGGL(k_score_mfma, dim3(cdiv(nslots, MS_POSES)), dim3(MS_THREADS), 0, io.stream, q, ctx->centre, (const uint4 *)ctx->feat.p,
-                           ntiles, proj_dev, (const int *)io.vlist->p, (const unsigned int *)io.vcount->p, eps, counts_dev);
+                           (unsigned int *)io.vcount->p, counts_dev, gy > 1 ? 1 : 0);
+        hipLaunchKernelGGL(k_score_mfma, dim3(pose_batches, gy), dim3(MS_THREADS), 0, io.stream, q, ctx->centre, (const uint4 *)ctx->feat.p,
+                           ntiles, tpb, proj_dev, (const int *)io.vlist->p, (const unsigned int *)io.vcount->p, eps, counts_dev);
         HIPCHK(ctx, hipGetLastError());
         return POSE_AMD_OK;
     }

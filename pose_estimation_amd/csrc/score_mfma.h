@@ -102,10 +102,11 @@ __global__ void k_make_feat(query_dev q, query_centre qc, int ntiles, uint4 *__r
 
 // Dense list of the valid pose slots (slot % maxsol < nsol[slot / maxsol]); order unspecified.
 // A block of 256 threads handles MS_COMPACT_SLOTS consecutive slots with one atomic reservation.
-// counts[] of the slots that are not valid is set to 0 (the scoring kernel writes the others).
+// counts[] of the slots that are not valid is set to 0 (the scoring kernel writes the others), of
+// all slots when zero_all is set (the scoring kernel then adds to them from several blocks).
 constexpr int MS_COMPACT_SLOTS = 4096;
 __global__ __launch_bounds__(256) void k_compact_valid(int nslots, const int *__restrict__ nsol, int maxsol, int *__restrict__ vlist,
-                                                       unsigned int *__restrict__ counter, int *__restrict__ counts)
+                                                       unsigned int *__restrict__ counter, int *__restrict__ counts, int zero_all)
 {
     __shared__ int s_n[4];
     __shared__ unsigned s_base;
@@ -115,8 +116,9 @@ __global__ __launch_bounds__(256) void k_compact_valid(int nslots, const int *__
 #pragma unroll
     for (int k = 0; k < MS_COMPACT_SLOTS / 256; ++k) {
         const int slot = slot0 + 256 * k;
-        if (slot < nslots && (!nsol || (slot % maxsol) < nsol[slot / maxsol])) valid |= 1u << k;
-        else if (slot < nslots) counts[slot] = 0;
+        const bool ok = slot < nslots && (!nsol || (slot % maxsol) < nsol[slot / maxsol]);
+        if (ok) valid |= 1u << k;
+        if (slot < nslots && (!ok || zero_all)) counts[slot] = 0;
     }
     const int mine = __popc(valid);
     // exclusive prefix of `mine` inside the wave
@@ -214,7 +216,7 @@ __device__ __forceinline__ bool ms_exact_inlier(const query_dev &q, const double
 // matrix instructions of a tile are issued back to back so that the vector work on the first
 // group's result overlaps the second group's products.
 __global__ __launch_bounds__(MS_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_score_mfma(
-    query_dev q, query_centre qc, const uint4 *__restrict__ feat, int ntiles, const double *__restrict__ proj,
+    query_dev q, query_centre qc, const uint4 *__restrict__ feat, int ntiles, int tiles_per_block, const double *__restrict__ proj,
     const int *__restrict__ vlist, const unsigned int *__restrict__ nvalid_p, double eps, int *__restrict__ counts)
 {
     __shared__ uint4 s_feat[MS_CHUNK_TILES * MS_TILE_BYTES / 16];
@@ -297,8 +299,11 @@ __global__ __launch_bounds__(MS_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
         }
     };
 
-    for (int chunk0 = 0; chunk0 < ntiles; chunk0 += MS_CHUNK_TILES) {
-        const int ct = min(MS_CHUNK_TILES, ntiles - chunk0);
+    // blockIdx.y selects the block's share of the correspondences (small launches are spread over
+    // the chip that way; the counts of a pose are then added up from several blocks)
+    const int tile_end = min(ntiles, ((int)blockIdx.y + 1) * tiles_per_block);
+    for (int chunk0 = (int)blockIdx.y * tiles_per_block; chunk0 < tile_end; chunk0 += MS_CHUNK_TILES) {
+        const int ct = min(MS_CHUNK_TILES, tile_end - chunk0);
         __syncthreads();                                 // everybody is done with the previous chunk
         for (int i = tid; i < ct * (MS_TILE_BYTES / 16); i += MS_THREADS) s_feat[i] = feat[(size_t)chunk0 * (MS_TILE_BYTES / 16) + i];
         __syncthreads();
@@ -329,7 +334,11 @@ __global__ __launch_bounds__(MS_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
     __builtin_amdgcn_wave_barrier();
     drain(qn);
     __syncthreads();
-    for (int i = tid; i < nblk; i += MS_THREADS) counts[s_slot[i]] = s_cnt[i];
+    if (gridDim.y == 1) {
+        for (int i = tid; i < nblk; i += MS_THREADS) counts[s_slot[i]] = s_cnt[i];
+    } else {
+        for (int i = tid; i < nblk; i += MS_THREADS) if (s_cnt[i]) atomicAdd(&counts[s_slot[i]], s_cnt[i]);
+    }
 }
 
 } // namespace pose_amd
