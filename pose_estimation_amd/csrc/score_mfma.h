@@ -44,6 +44,7 @@ constexpr int MS_POSES = MS_WAVES * MS_GROUPS * 32;   // 512 poses per block
 constexpr int MS_TILE_BYTES = 1536;                // features of 32 correspondences: A1 | A2 (lanes 0..31) | A2 (lanes 32..63)
 constexpr int MS_CHUNK_TILES = 32;                 // tiles staged in LDS at a time (48 KB)
 constexpr int MS_QUEUE = 128;                      // queue entries per wave
+constexpr int MS_DENSE_ROWS = 4;                  // open pairs among a lane's 16 of one tile that take a pose off the screen
 constexpr int MS_MAX_N = 1 << 17;                  // correspondence index bits in a queue entry
 constexpr float MS_PAD_U = 1.0e9f;                 // u of the padding correspondences (certified outside unless t2 == 0)
 
@@ -222,6 +223,7 @@ __global__ __launch_bounds__(MS_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
     __shared__ uint4 s_feat[MS_CHUNK_TILES * MS_TILE_BYTES / 16];
     __shared__ int s_cnt[MS_POSES];
     __shared__ int s_slot[MS_POSES];
+    __shared__ int s_dense[MS_POSES];                       // first correspondence of the pose's float64 scan
     __shared__ unsigned s_queue[MS_WAVES][MS_QUEUE + 64];   // + one scratch word per lane
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const bool upper = lane >= 32;
@@ -231,8 +233,17 @@ __global__ __launch_bounds__(MS_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
     const int nblk = min(MS_POSES, nvalid - first);
     for (int i = tid; i < MS_POSES; i += MS_THREADS) {
         s_cnt[i] = 0;
+        s_dense[i] = 0x7fffffff;
         s_slot[i] = i < nblk ? vlist[first + i] : -1;
     }
+    // blockIdx.y selects the block's share of the correspondences (small launches are spread over
+    // the chip that way; the counts of a pose are then added up from several blocks)
+    const int tile_begin = (int)blockIdx.y * tiles_per_block;
+    const int tile_end = min(ntiles, tile_begin + tiles_per_block);
+    auto stage = [&](int chunk0, int ct) {
+        for (int i = tid; i < ct * (MS_TILE_BYTES / 16); i += MS_THREADS) s_feat[i] = feat[(size_t)chunk0 * (MS_TILE_BYTES / 16) + i];
+    };
+    stage(tile_begin, min(MS_CHUNK_TILES, tile_end - tile_begin));   // in flight together with the slot list
     __syncthreads();
     ms_pose_ops ops[MS_GROUPS];
     const int pl0 = wave * (32 * MS_GROUPS) + (lane & 31);    // the lane's pose of group 0; group g: + 32 g
@@ -259,7 +270,13 @@ __global__ __launch_bounds__(MS_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
     // screens one 32 x 32 result and queues what it cannot certify
     const unsigned qaddr = (unsigned)(size_t)queue;      // LDS byte address of the wave's queue
     const unsigned dummy = qaddr + (MS_QUEUE + lane) * 4;   // where lanes without a pair to queue write
-    auto screen = [&](const f32x16 &rx, const f32x16 &pz, float c, int pl, int mbase) {
+    // A pose with MS_DENSE_ROWS or more uncertified pairs among a lane's 16 of one tile (a pose
+    // with many inliers: chance alone leaves about one pair in five hundred open) stops being
+    // screened: its operands are zeroed and its constant set to -inf, which certifies every later
+    // pair, and its remaining correspondences are decided by the float64 test in one coalesced
+    // pass at the end, which costs less than queueing them one by one.
+    auto screen = [&](const f32x16 &rx, const f32x16 &pz, ms_pose_ops &op, int pl, int mbase) {
+        const float c = op.c;
         unsigned long long open[16];
         unsigned long long any4[4] = {0, 0, 0, 0};
 #pragma unroll
@@ -269,6 +286,7 @@ __global__ __launch_bounds__(MS_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
             any4[r / 4] |= open[r];
         }
         if ((any4[0] | any4[1]) | (any4[2] | any4[3])) {
+            int mycnt = 0;
             const unsigned ent = ((unsigned)pl << 17) | (unsigned)mbase;
 #pragma unroll
             for (int r4 = 0; r4 < 4; ++r4) {
@@ -282,6 +300,7 @@ __global__ __launch_bounds__(MS_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
                     // the ones without a pair store to a scratch word of their own.
                     const unsigned pos = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
                     const bool mine = (m >> lane) & 1ull;
+                    mycnt += mine ? 1 : 0;
                     const unsigned addr = mine ? qaddr + ((unsigned)qn + pos) * 4u : dummy;
                     *reinterpret_cast<__attribute__((address_space(3))) unsigned *>((uintptr_t)addr) = ent + (unsigned)(8 * r4 + rr);
                     qn = __builtin_amdgcn_readfirstlane(qn + __popcll(m));
@@ -296,17 +315,25 @@ __global__ __launch_bounds__(MS_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
                     }
                 }
             }
+            const unsigned long long dl = __ballot(mycnt >= MS_DENSE_ROWS);
+            if (dl) {
+                const unsigned pm = (unsigned)dl | (unsigned)(dl >> 32);          // both lanes of a pose leave
+                if ((pm >> (lane & 31)) & 1u) {
+                    s_dense[pl] = (mbase & ~31) + 32;                             // this tile's pairs are queued already
+                    op.c = -__builtin_inff();
+                    op.b1 = op.b2 = op.bz = bf16x8{};
+                }
+            }
         }
     };
 
-    // blockIdx.y selects the block's share of the correspondences (small launches are spread over
-    // the chip that way; the counts of a pose are then added up from several blocks)
-    const int tile_end = min(ntiles, ((int)blockIdx.y + 1) * tiles_per_block);
-    for (int chunk0 = (int)blockIdx.y * tiles_per_block; chunk0 < tile_end; chunk0 += MS_CHUNK_TILES) {
+    for (int chunk0 = tile_begin; chunk0 < tile_end; chunk0 += MS_CHUNK_TILES) {
         const int ct = min(MS_CHUNK_TILES, tile_end - chunk0);
-        __syncthreads();                                 // everybody is done with the previous chunk
-        for (int i = tid; i < ct * (MS_TILE_BYTES / 16); i += MS_THREADS) s_feat[i] = feat[(size_t)chunk0 * (MS_TILE_BYTES / 16) + i];
-        __syncthreads();
+        if (chunk0 != tile_begin) {                      // the first chunk was staged before the poses were prepared
+            __syncthreads();                             // everybody is done with the previous chunk
+            stage(chunk0, ct);
+            __syncthreads();
+        }
         if (!live) continue;
         // Skewed by half a step so that matrix and vector work interleave inside the wave: while
         // group 0's products of tile t are in the matrix pipe the wave screens group 1's result of
@@ -321,18 +348,34 @@ __global__ __launch_bounds__(MS_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
             rx0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, ops[0].b1, zero, 0, 0, 0);
             pz0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, ops[0].bz, zero, 0, 0, 0);
             rx0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, ops[0].b2, rx0, 0, 0, 0);
-            if (t > 0) screen(rx1, pz1, ops[1].c, pl0 + 32, mbase - 32);
+            if (t > 0) screen(rx1, pz1, ops[1], pl0 + 32, mbase - 32);
             MS_INTERLEAVE();
             rx1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, ops[1].b1, zero, 0, 0, 0);
             pz1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, ops[1].bz, zero, 0, 0, 0);
             rx1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, ops[1].b2, rx1, 0, 0, 0);
-            screen(rx0, pz0, ops[0].c, pl0, mbase);
+            screen(rx0, pz0, ops[0], pl0, mbase);
             MS_INTERLEAVE();
         }
-        screen(rx1, pz1, ops[1].c, pl0 + 32, (chunk0 + ct - 1) * 32 + (upper ? 4 : 0));
+        screen(rx1, pz1, ops[1], pl0 + 32, (chunk0 + ct - 1) * 32 + (upper ? 4 : 0));
     }
     __builtin_amdgcn_wave_barrier();
     drain(qn);
+    {
+        // the poses that left the screen: float64 test of their remaining correspondences, 64 at a time
+        const int dstart = s_dense[wave * (32 * MS_GROUPS) + lane];
+        const int dend = min(q.n, tile_end * 32);
+        unsigned long long dm = __ballot(dstart < dend);
+        while (dm) {
+            const int l = __builtin_ctzll(dm);
+            dm &= dm - 1;
+            const int pl = wave * (32 * MS_GROUPS) + l;
+            const int slot = s_slot[pl];
+            int total = 0;
+            for (int base = __builtin_amdgcn_readlane(dstart, l); base < dend; base += 64)
+                total += __popcll(__ballot(base + lane < dend && ms_exact_inlier(q, proj, slot, base + lane, eps)));
+            if (lane == 0) atomicAdd(&s_cnt[pl], total);
+        }
+    }
     __syncthreads();
     if (gridDim.y == 1) {
         for (int i = tid; i < nblk; i += MS_THREADS) counts[s_slot[i]] = s_cnt[i];
