@@ -459,10 +459,11 @@ def test_score_screen_equals_float64_kernel(ctx):
 
 
 def test_score_matrix_core_screen_equals_float64_kernel(ctx):
-    """Launches large enough for the matrix-core screen (no masks, >= 131072 poses) must count
-    exactly what the float64-only kernel counts: poses at all distances from the truth, world
-    coordinates far from the origin, odd sizes, and poses with NaN, infinite, huge, tiny and zero
-    entries."""
+    """Launches large enough for the matrix-core screen (no masks, >= 8192 poses) must count
+    exactly what the float64-only kernel counts: poses at all distances from the truth (those
+    near it leave the screen for the float64 pass), world coordinates far from the origin, odd
+    sizes, poses with NaN, infinite, huge, tiny and zero entries; launches small enough to be cut
+    along the correspondences as well as ones of whole-range blocks."""
     from pose_estimation_amd import Context
     os.environ["POSE_AMD_SCORE"] = "fp64"
     try:
@@ -499,6 +500,12 @@ def test_score_matrix_core_screen_equals_float64_kernel(ctx):
                 c0 = ref_ctx.score_batch(P, eps, want_masks=False)
                 assert np.array_equal(c1, c0)
                 assert c0.max() > 0.1 * n and c0[5] == 0 and c0[6] == 0 and c0[10] == 0
+            # few poses: every block takes a share of the correspondences
+            assert np.array_equal(ctx.score_batch(P[:9001], 0.5, want_masks=False), ref_ctx.score_batch(P[:9001], 0.5, want_masks=False))
+            if n == 4099:
+                # many poses: every block walks all the correspondences, several chunks of them
+                Pbig = np.tile(P, (5, 1, 1))[:530001]
+                assert np.array_equal(ctx.score_batch(Pbig, 0.5, want_masks=False), ref_ctx.score_batch(Pbig, 0.5, want_masks=False))
 
 
 def test_two_stream_split_gives_the_same_run(ctx):
