@@ -443,8 +443,13 @@ static int launch_score(pose_amd_ctx *ctx, const lane_io &io, int nslots, const 
         int rc;
         const int ntiles = cdiv(ctx->n, 32);
         if ((rc = ensure_feat(ctx, io.stream))) return rc;
-        if ((rc = ensure(ctx, *io.vlist, (size_t)nslots * 4)) || (rc = ensure(ctx, *io.vcount, 4))) return rc;
-        HIPCHK(ctx, hipMemsetAsync(io.vcount->p, 0, 4, io.stream));
+        // the slot list is allocated in whole blocks: the scoring kernel reads it ahead of the count
+        if ((rc = ensure(ctx, *io.vlist, (size_t)cdiv(nslots, MS_POSES) * MS_POSES * 4))) return rc;
+        if (!io.vcount->p) {
+            // {valid poses, blocks done}: zeroed once, the scoring kernel's last block re-arms it
+            if ((rc = ensure(ctx, *io.vcount, 8))) return rc;
+            HIPCHK(ctx, hipMemsetAsync(io.vcount->p, 0, 8, io.stream));
+        }
         // a launch with few poses is also cut along the correspondences, so that it still has a
         // thousand blocks or so; their counts are then added up with atomics
         const int pose_batches = cdiv(nslots, MS_POSES), nchunks = cdiv(ntiles, MS_CHUNK_TILES);
@@ -454,7 +459,7 @@ static int launch_score(pose_amd_ctx *ctx, const lane_io &io, int nslots, const 
         hipLaunchKernelGGL(k_compact_valid, dim3(cdiv(nslots, MS_COMPACT_SLOTS)), dim3(256), 0, io.stream, nslots, nsol_dev, maxsol, (int *)io.vlist->p,
                            (unsigned int *)io.vcount->p, counts_dev, gy > 1 ? 1 : 0);
         hipLaunchKernelGGL(k_score_mfma, dim3(pose_batches, gy), dim3(MS_THREADS), 0, io.stream, q, ctx->centre, (const uint4 *)ctx->feat.p,
-                           ntiles, tpb, proj_dev, (const int *)io.vlist->p, (const unsigned int *)io.vcount->p, eps, counts_dev);
+                           ntiles, tpb, proj_dev, (const int *)io.vlist->p, (unsigned int *)io.vcount->p, eps, counts_dev);
         HIPCHK(ctx, hipGetLastError());
         return POSE_AMD_OK;
     }

@@ -218,7 +218,7 @@ __device__ __forceinline__ bool ms_exact_inlier(const query_dev &q, const double
 // group's result overlaps the second group's products.
 __global__ __launch_bounds__(MS_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_score_mfma(
     query_dev q, query_centre qc, const uint4 *__restrict__ feat, int ntiles, int tiles_per_block, const double *__restrict__ proj,
-    const int *__restrict__ vlist, const unsigned int *__restrict__ nvalid_p, double eps, int *__restrict__ counts)
+    const int *__restrict__ vlist, unsigned int *__restrict__ nvalid_p, double eps, int *__restrict__ counts)
 {
     __shared__ uint4 s_feat[MS_CHUNK_TILES * MS_TILE_BYTES / 16];
     __shared__ int s_cnt[MS_POSES];
@@ -227,15 +227,29 @@ __global__ __launch_bounds__(MS_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
     __shared__ unsigned s_queue[MS_WAVES][MS_QUEUE + 64];   // + one scratch word per lane
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const bool upper = lane >= 32;
-    const int nvalid = (int)*nvalid_p;
+    static_assert(MS_POSES == MS_THREADS, "one slot-list entry per thread");
     const int first = blockIdx.x * MS_POSES;
-    if (first >= nvalid) return;                         // whole blocks leave together
+    const int pl0 = wave * (32 * MS_GROUPS) + (lane & 31);    // the lane's pose of group 0; group g: + 32 g
+    // The slot list is read ahead of the valid count (it is allocated in whole blocks), so that
+    // the two loads and the pose loads that depend on them are one round trip shorter.
+    const int lslot = vlist[first + tid];
+    int myslot[MS_GROUPS];
+#pragma unroll
+    for (int g = 0; g < MS_GROUPS; ++g) myslot[g] = vlist[first + pl0 + 32 * g];
+    const int nvalid = (int)*nvalid_p;
+    // nvalid_p[1] counts the blocks that are done; the last one zeroes both words for the next
+    // launch on this stream (every block has read the count by then)
+    auto leave = [&]() {
+        if (tid == 0 && atomicAdd(&nvalid_p[1], 1u) == gridDim.x * gridDim.y - 1) {
+            __hip_atomic_store(&nvalid_p[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&nvalid_p[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    };
+    if (first >= nvalid) { leave(); return; }            // whole blocks leave together
     const int nblk = min(MS_POSES, nvalid - first);
-    for (int i = tid; i < MS_POSES; i += MS_THREADS) {
-        s_cnt[i] = 0;
-        s_dense[i] = 0x7fffffff;
-        s_slot[i] = i < nblk ? vlist[first + i] : -1;
-    }
+    s_cnt[tid] = 0;
+    s_dense[tid] = 0x7fffffff;
+    s_slot[tid] = tid < nblk ? lslot : -1;
     // blockIdx.y selects the block's share of the correspondences (small launches are spread over
     // the chip that way; the counts of a pose are then added up from several blocks)
     const int tile_begin = (int)blockIdx.y * tiles_per_block;
@@ -243,16 +257,15 @@ __global__ __launch_bounds__(MS_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
     auto stage = [&](int chunk0, int ct) {
         for (int i = tid; i < ct * (MS_TILE_BYTES / 16); i += MS_THREADS) s_feat[i] = feat[(size_t)chunk0 * (MS_TILE_BYTES / 16) + i];
     };
-    stage(tile_begin, min(MS_CHUNK_TILES, tile_end - tile_begin));   // in flight together with the slot list
-    __syncthreads();
+    stage(tile_begin, min(MS_CHUNK_TILES, tile_end - tile_begin));   // in flight together with the poses
     ms_pose_ops ops[MS_GROUPS];
-    const int pl0 = wave * (32 * MS_GROUPS) + (lane & 31);    // the lane's pose of group 0; group g: + 32 g
     const bool live = wave * (32 * MS_GROUPS) < nblk;         // wave-uniform: the wave has at least one pose
 #pragma unroll
     for (int g = 0; g < MS_GROUPS; ++g) {
         const int pl = pl0 + 32 * g;
-        ms_prepare(proj, pl < nblk ? s_slot[pl] : 0, pl < nblk, q, qc, eps, upper, ops[g]);
+        ms_prepare(proj, pl < nblk ? myslot[g] : 0, pl < nblk, q, qc, eps, upper, ops[g]);
     }
+    __syncthreads();
     // eps rounded up and widened for the float32 evaluation of eps |pz| + c
     const double epd = eps * (1.0 + 2.384185791015625e-07);
     float epf = (float)epd;
@@ -382,6 +395,7 @@ __global__ __launch_bounds__(MS_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
     } else {
         for (int i = tid; i < nblk; i += MS_THREADS) if (s_cnt[i]) atomicAdd(&counts[s_slot[i]], s_cnt[i]);
     }
+    leave();
 }
 
 } // namespace pose_amd
