@@ -759,15 +759,119 @@ __global__ __launch_bounds__(SCORE_THREADS) __attribute__((amdgpu_waves_per_eu(6
 }
 
 // ------------------------------------------------------------------------------------------
-// Coverage area (query_processor.cpp:126-169): one block per pose paints the clamped
-// coverage boxes of the pose's inliers into a private bitmap in global memory and counts
-// the set bits.  all_matches != 0 paints every correspondence (the match_area map).
+// Coverage area (query_processor.cpp:126-169): the number of pixels covered by the clamped
+// coverage boxes of a pose's inliers.  all_matches != 0 takes every correspondence (the
+// match_area map).  With `slots` the i-th pose is proj[slots[i]] (candidates picked out of a
+// chunk).  blockIdx.y selects a band of `band_rows` image rows; the band sums are added up in
+// areas[pose] (zeroed by the host beforehand).  Nothing but the sums leaves the chip.
+//
+// All boxes have the same half width h = ceil(width / 20) / 2 in both directions, and a box is
+// the product of a column interval that depends on x only and a row interval that depends on
+// y only: columns [clamp(x - h), clamp(x + h)), rows [clamp(y - h), clamp(y + h)), clamped to
+// [0, width - 1] and [0, height - 1].  Row r <= height - 2 therefore lies in the boxes of exactly
+// the keypoints with y in [r - h + 1, r + h], and the covered columns of row r are the union of
+// their column intervals.  k_coverage paints each inlier's column interval once, into the row
+// of its own y (a few LDS atomics per inlier instead of a few per inlier and row), and then
+// forms every output row as the union of the 2h rows above it -- through unions of aligned
+// groups of eight rows, about 24 reads per word -- and counts its bits.
+//
+// k_coverage_direct paints whole boxes into the band's bitmap; it is kept for images so wide
+// that the 2h extra rows of a band do not fit the LDS.
 // ------------------------------------------------------------------------------------------
-// With `slots` the i-th pose is proj[slots[i]] (candidate poses picked out of a chunk).
-// The bitmap never leaves the chip: blockIdx.y selects a band of `band_rows` image rows whose
-// bitmap (band_rows x words_per_row words, dynamic LDS) is painted with LDS atomics and counted
-// in place; the band sums are added up in areas[pose] (zeroed by the host beforehand).
+constexpr int COV_UNROLL = 8;
 __global__ __launch_bounds__(256) void k_coverage(query_dev q, int nposes, const double *__restrict__ proj, const int *__restrict__ slots,
+                                                  double eps, int all_matches, int band_rows, int words_per_row,
+                                                  unsigned long long *__restrict__ areas)
+{
+    extern __shared__ unsigned int s_bm[];                   // nh painted rows, then ng rows of group unions
+    __shared__ unsigned long long s_sum[4];
+    __shared__ int s_any;
+    const int pose = blockIdx.x;
+    if (pose >= nposes) return;
+    const int tid = threadIdx.x;
+    const int row0 = blockIdx.y * band_rows, row1 = min(q.height, row0 + band_rows);
+    const int cover = (int)ceilf((float)q.width / 20.0f), h = cover / 2;
+    if (h == 0) return;                                      // every box is empty
+    const int nh = (row1 - row0) + 2 * h - 1;                // keypoint rows y_base .. y_base + nh - 1 reach into the band
+    const int ng = (nh + 7) >> 3;
+    const int y_base = row0 - h + 1;
+    unsigned int *Hm = s_bm, *G = s_bm + nh * words_per_row;
+    for (int i = tid; i < (nh + ng) * words_per_row; i += blockDim.x) s_bm[i] = 0u;
+    if (tid == 0) s_any = 0;
+    __syncthreads();
+    const double hw = (double)q.width / 2.0, hh = (double)q.height / 2.0;
+    const double *P = proj + (size_t)(slots ? slots[pose] : pose) * 12;
+    // COV_UNROLL correspondences per thread and pass, their loads issued together
+    for (int i0 = tid; i0 < q.n; i0 += COV_UNROLL * blockDim.x) {
+        float kxs[COV_UNROLL], kys[COV_UNROLL], Xs[COV_UNROLL], Ys[COV_UNROLL], Zs[COV_UNROLL];
+#pragma unroll
+        for (int k = 0; k < COV_UNROLL; ++k) {
+            const int i = min(i0 + k * (int)blockDim.x, q.n - 1);
+            kxs[k] = q.kx[i]; kys[k] = q.ky[i];
+            if (!all_matches) { Xs[k] = q.X[i]; Ys[k] = q.Y[i]; Zs[k] = q.Z[i]; }
+        }
+#pragma unroll
+        for (int k = 0; k < COV_UNROLL; ++k) {
+            if (i0 + k * (int)blockDim.x >= q.n) break;
+            const int x = (int)rintf(kxs[k]), y = (int)rintf(kys[k]);
+            const int sx = max(0, min(x - h, q.width - 1)), sy = max(0, min(y - h, q.height - 1));
+            const int ex = max(0, min(x + h, q.width - 1)), ey = max(0, min(y + h, q.height - 1));
+            if (!(sy < ey && sx < ex)) continue;
+            const int yy = y - y_base;
+            if (yy < 0 || yy >= nh) continue;                    // the box does not touch this band
+            if (!all_matches) {
+                const double X = Xs[k], Y = Ys[k], Z = Zs[k];
+                const double u = -((double)kxs[k] - hw), v = -((double)kys[k] - hh);
+                const double px = fma(P[0], X, fma(P[1], Y, fma(P[2], Z, P[3])));
+                const double py = fma(P[4], X, fma(P[5], Y, fma(P[6], Z, P[7])));
+                const double pz = fma(P[8], X, fma(P[9], Y, fma(P[10], Z, P[11])));
+                const double rx = fma(u, pz, -px), ry = fma(v, pz, -py);
+                const double te = eps * pz;
+                if (!(fma(ry, ry, rx * rx) < te * te)) continue;
+            }
+            const int w0 = sx >> 5, w1 = (ex - 1) >> 5;
+            for (int w = w0; w <= w1; ++w) {
+                unsigned int bits = 0xFFFFFFFFu;
+                if (w == w0) bits &= 0xFFFFFFFFu << (sx & 31);
+                if (w == w1) bits &= 0xFFFFFFFFu >> (31 - ((ex - 1) & 31));
+                atomicOr(&Hm[yy * words_per_row + w], bits);
+            }
+            s_any = 1;
+        }
+    }
+    __syncthreads();
+    if (!s_any) return;                                      // no inlier near this band
+    for (int t = tid; t < ng * words_per_row; t += blockDim.x) {
+        const int g = t / words_per_row, c = t - g * words_per_row;
+        unsigned int v = 0;
+        for (int yy = 8 * g; yy < min(nh, 8 * g + 8); ++yy) v |= Hm[yy * words_per_row + c];
+        G[t] = v;
+    }
+    __syncthreads();
+    // output row row0 + rr is the union of painted rows rr .. rr + 2h - 1; the last image row is never covered
+    const int rows_out = min(row1, q.height - 1) - row0;
+    unsigned long long a = 0;
+    for (int t = tid; t < rows_out * words_per_row; t += blockDim.x) {
+        const int rr = t / words_per_row, c = t - rr * words_per_row;
+        const int hi = rr + 2 * h;
+        int yy = rr;
+        unsigned int v = 0;
+        while (yy < hi && (yy & 7)) { v |= Hm[yy * words_per_row + c]; ++yy; }
+        while (yy + 8 <= hi) { v |= G[(yy >> 3) * words_per_row + c]; yy += 8; }
+        while (yy < hi) { v |= Hm[yy * words_per_row + c]; ++yy; }
+        a += __popc(v);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o);
+    if ((tid & 63) == 0) s_sum[tid >> 6] = a;
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned long long sum = s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3];
+        if (sum) atomicAdd(&areas[pose], sum);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_coverage_direct(query_dev q, int nposes, const double *__restrict__ proj, const int *__restrict__ slots,
                                                   double eps, int all_matches, int band_rows, int words_per_row,
                                                   unsigned long long *__restrict__ areas)
 {
@@ -783,30 +887,43 @@ __global__ __launch_bounds__(256) void k_coverage(query_dev q, int nposes, const
     const double hw = (double)q.width / 2.0, hh = (double)q.height / 2.0;
     const double *P = proj + (size_t)(slots ? slots[pose] : pose) * 12;
     const int cover = (int)ceilf((float)q.width / 20.0f);
-    for (int i = tid; i < q.n; i += blockDim.x) {
-        const int x = (int)rintf(q.kx[i]), y = (int)rintf(q.ky[i]);
-        const int sx = max(0, min(x - cover / 2, q.width - 1)), sy = max(0, min(y - cover / 2, q.height - 1));
-        const int ex = max(0, min(x + cover / 2, q.width - 1)), ey = max(0, min(y + cover / 2, q.height - 1));
-        if (!(sy < ey && sx < ex)) continue;
-        const int r0 = max(sy, row0), r1 = min(ey, row1);
-        if (r0 >= r1) continue;                              // the box does not touch this band
-        if (!all_matches) {
-            const double X = q.X[i], Y = q.Y[i], Z = q.Z[i];
-            const double u = -((double)q.kx[i] - hw), v = -((double)q.ky[i] - hh);
-            const double px = fma(P[0], X, fma(P[1], Y, fma(P[2], Z, P[3])));
-            const double py = fma(P[4], X, fma(P[5], Y, fma(P[6], Z, P[7])));
-            const double pz = fma(P[8], X, fma(P[9], Y, fma(P[10], Z, P[11])));
-            const double rx = fma(u, pz, -px), ry = fma(v, pz, -py);
-            const double te = eps * pz;
-            if (!(fma(ry, ry, rx * rx) < te * te)) continue;
+    // COV_UNROLL correspondences per thread and pass, their loads issued together: with few
+    // inliers the kernel is a chain of load latencies, not arithmetic or painting.
+    for (int i0 = tid; i0 < q.n; i0 += COV_UNROLL * blockDim.x) {
+        float kxs[COV_UNROLL], kys[COV_UNROLL], Xs[COV_UNROLL], Ys[COV_UNROLL], Zs[COV_UNROLL];
+#pragma unroll
+        for (int k = 0; k < COV_UNROLL; ++k) {
+            const int i = min(i0 + k * (int)blockDim.x, q.n - 1);
+            kxs[k] = q.kx[i]; kys[k] = q.ky[i];
+            if (!all_matches) { Xs[k] = q.X[i]; Ys[k] = q.Y[i]; Zs[k] = q.Z[i]; }
         }
-        const int w0 = sx >> 5, w1 = (ex - 1) >> 5;
-        for (int r = r0; r < r1; ++r) {
-            for (int w = w0; w <= w1; ++w) {
-                unsigned int bits = 0xFFFFFFFFu;
-                if (w == w0) bits &= 0xFFFFFFFFu << (sx & 31);
-                if (w == w1) bits &= 0xFFFFFFFFu >> (31 - ((ex - 1) & 31));
-                atomicOr(&s_bm[(r - row0) * words_per_row + w], bits);
+#pragma unroll
+        for (int k = 0; k < COV_UNROLL; ++k) {
+            if (i0 + k * (int)blockDim.x >= q.n) break;
+            const int x = (int)rintf(kxs[k]), y = (int)rintf(kys[k]);
+            const int sx = max(0, min(x - cover / 2, q.width - 1)), sy = max(0, min(y - cover / 2, q.height - 1));
+            const int ex = max(0, min(x + cover / 2, q.width - 1)), ey = max(0, min(y + cover / 2, q.height - 1));
+            if (!(sy < ey && sx < ex)) continue;
+            const int r0 = max(sy, row0), r1 = min(ey, row1);
+            if (r0 >= r1) continue;                              // the box does not touch this band
+            if (!all_matches) {
+                const double X = Xs[k], Y = Ys[k], Z = Zs[k];
+                const double u = -((double)kxs[k] - hw), v = -((double)kys[k] - hh);
+                const double px = fma(P[0], X, fma(P[1], Y, fma(P[2], Z, P[3])));
+                const double py = fma(P[4], X, fma(P[5], Y, fma(P[6], Z, P[7])));
+                const double pz = fma(P[8], X, fma(P[9], Y, fma(P[10], Z, P[11])));
+                const double rx = fma(u, pz, -px), ry = fma(v, pz, -py);
+                const double te = eps * pz;
+                if (!(fma(ry, ry, rx * rx) < te * te)) continue;
+            }
+            const int w0 = sx >> 5, w1 = (ex - 1) >> 5;
+            for (int r = r0; r < r1; ++r) {
+                for (int w = w0; w <= w1; ++w) {
+                    unsigned int bits = 0xFFFFFFFFu;
+                    if (w == w0) bits &= 0xFFFFFFFFu << (sx & 31);
+                    if (w == w1) bits &= 0xFFFFFFFFu >> (31 - ((ex - 1) & 31));
+                    atomicOr(&s_bm[(r - row0) * words_per_row + w], bits);
+                }
             }
         }
     }

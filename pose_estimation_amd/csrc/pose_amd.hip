@@ -519,20 +519,34 @@ static int coverage_dev(pose_amd_ctx *ctx, int nposes, const double *proj_dev, d
     int rc;
     if ((rc = ensure(ctx, ctx->areas, (size_t)nposes * 8))) return rc;
     HIPCHK(ctx, hipMemsetAsync(ctx->areas.p, 0, (size_t)nposes * 8, ctx->stream));
-    // Bands of image rows: at most what fits 48 KB of LDS (three blocks per compute unit); thinner
-    // when few poses are evaluated, so that about 2 000 blocks exist and a single pose (the
-    // all-matches map, a candidate with thousands of inliers) is not painted by a handful of them.
+    // Bands of image rows.  A band of R rows needs R + 2h - 1 painted rows (h: half box width) plus
+    // one row of unions per eight of them in LDS, 64 KB at most; thinner bands when few poses are
+    // evaluated, so that about 2 000 blocks exist and a single pose (the all-matches map) is not
+    // left to a handful of them.  Images too wide for that (the 2h extra rows alone exceed the
+    // LDS) take the kernel that paints whole boxes into a band bitmap of at most 48 KB.
     if ((size_t)wpr * 4 > 48 * 1024) return fail(ctx, POSE_AMD_EINVAL, "coverage: image wider than 393216 px");
-    const int max_rows = std::max(1, std::min(ctx->height, (48 * 1024) / (wpr * 4)));
+    const int half = (int)std::ceil((float)ctx->width / 20.0f) / 2;
+    const int lds_rows = (64 * 1024) / (wpr * 4);                       // rows of words_per_row words in 64 KB
+    const int sep_rows = (lds_rows * 8) / 9 - 2 * half - 1;             // band rows the separable kernel can take
+    const bool separable = sep_rows >= 8;
+    const int max_rows = separable ? std::min(ctx->height, sep_rows) : std::max(1, std::min(ctx->height, (48 * 1024) / (wpr * 4)));
     const int chunk_max = 16384;
     for (int p0 = 0; p0 < nposes; p0 += chunk_max) {
         const int cn = nposes - p0 < chunk_max ? nposes - p0 : chunk_max;
         const int want_bands = std::min(cdiv(ctx->height, 8), cdiv(2048, cn));
         const int band_rows = std::max(1, std::min(max_rows, cdiv(ctx->height, std::max(1, want_bands))));
         const int bands = cdiv(ctx->height, band_rows);
-        hipLaunchKernelGGL(k_coverage, dim3(cn, bands), dim3(256), (size_t)band_rows * wpr * 4, ctx->stream, q, cn,
-                           slots_dev ? proj_dev : proj_dev + (size_t)p0 * 12, slots_dev ? slots_dev + p0 : nullptr, eps, all_matches,
-                           band_rows, wpr, (unsigned long long *)ctx->areas.p + p0);
+        const double *pd = slots_dev ? proj_dev : proj_dev + (size_t)p0 * 12;
+        const int *sd = slots_dev ? slots_dev + p0 : nullptr;
+        if (separable) {
+            const int nh = band_rows + 2 * half - 1;
+            const size_t lds = (size_t)(nh + (nh + 7) / 8) * wpr * 4;
+            hipLaunchKernelGGL(k_coverage, dim3(cn, bands), dim3(256), lds, ctx->stream, q, cn, pd, sd, eps, all_matches,
+                               band_rows, wpr, (unsigned long long *)ctx->areas.p + p0);
+        } else {
+            hipLaunchKernelGGL(k_coverage_direct, dim3(cn, bands), dim3(256), (size_t)band_rows * wpr * 4, ctx->stream, q, cn, pd, sd, eps,
+                               all_matches, band_rows, wpr, (unsigned long long *)ctx->areas.p + p0);
+        }
         HIPCHK(ctx, hipGetLastError());
     }
     if ((rc = download(ctx, areas_host, ctx->areas.p, (size_t)nposes * 8))) return rc;

@@ -232,6 +232,38 @@ def test_coverage_areas_exact(ctx):
             assert areas[i] == O.coverage_area(q["kx"], q["ky"], m0, w, h)
 
 
+def test_coverage_areas_exact_for_batches_borders_and_wide_images(ctx):
+    """Candidate batches (one block per pose and band of rows), keypoints on and beyond the image
+    borders, images of one to a few rows, and an image too wide for the row-union kernel (whole
+    boxes painted instead): every area equals the oracle's."""
+    rng = np.random.default_rng(17)
+    for (w, h, n, nposes) in ((1600, 1200, 3000, 300), (1200, 1600, 800, 40), (640, 3, 300, 5), (57, 1, 50, 3),
+                              (20, 200, 60, 3), (20001, 64, 400, 6)):
+        q = synth.make_query(n, 0.5, w + n, width=max(w, 64), height=max(h, 64), focal=0.75 * max(w, h, 64))
+        if w < 64 or h < 64:                 # tiny images: keypoints anywhere in and around them
+            q["width"], q["height"] = w, h
+            q["kx"] = rng.uniform(-3, w + 3, n).astype(np.float32)
+            q["ky"] = rng.uniform(-3, h + 3, n).astype(np.float32)
+        edge = np.array([[0, 0], [w - 1, h - 1], [w, h], [-1, -1], [w - 2, 0], [0, h - 2], [-w // 30, h // 2], [w + w // 30, h // 2],
+                         [w // 2, -h // 3], [w // 2, h + 5], [w // 40, h // 40 + 1], [w - 1 - w // 40, h - 1 - w // 40]], np.float32)
+        q["kx"][:len(edge)] = edge[:, 0]
+        q["ky"][:len(edge)] = edge[:, 1]
+        upload(ctx, q)
+        P = []
+        for i in range(nposes):
+            s = 10.0 ** rng.uniform(-9, -1)
+            P.append(O.compute_matrices(q["f_true"] * (1 + s * rng.normal()), q["C_true"] + 10 * s * rng.normal(size=3),
+                                        q["Rc_true"] @ synth.small_rotation(rng, s)) if i % 3 else rng.normal(size=(3, 4)))
+        P = np.array(P)
+        areas, area_all = ctx.coverage_batch(P, 0.5)
+        assert area_all == O.coverage_area(q["kx"], q["ky"], None, w, h)
+        for i in range(nposes):
+            c0, m0 = oracle_masks(q, P[i])
+            assert areas[i] == O.coverage_area(q["kx"], q["ky"], m0, w, h), (w, h, i)
+        if h > 3 and w > 100:
+            assert areas.max() > 0
+
+
 # ---- sampling -------------------------------------------------------------------------------
 @pytest.mark.parametrize("known_focal", [True, False])
 def test_basic_samples_bit_exact(ctx, known_focal):
