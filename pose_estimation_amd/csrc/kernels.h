@@ -848,18 +848,42 @@ __global__ __launch_bounds__(256) void k_coverage(query_dev q, int nposes, const
         G[t] = v;
     }
     __syncthreads();
-    // output row row0 + rr is the union of painted rows rr .. rr + 2h - 1; the last image row is never covered
+    // Output row row0 + rr is the union of painted rows rr .. rr + 2h - 1; the last image row is
+    // never covered.  A thread forms the eight output rows rr = 8k .. 8k + 7 of one column word
+    // together: with 2h = 8m + e their windows share the whole groups k + 1 .. k + m - 1, begin
+    // with a suffix of group k and end with the first e + j rows from row 8 (k + m) on.
     const int rows_out = min(row1, q.height - 1) - row0;
+    const int m = (2 * h) >> 3, e = (2 * h) & 7;
     unsigned long long a = 0;
-    for (int t = tid; t < rows_out * words_per_row; t += blockDim.x) {
-        const int rr = t / words_per_row, c = t - rr * words_per_row;
-        const int hi = rr + 2 * h;
-        int yy = rr;
-        unsigned int v = 0;
-        while (yy < hi && (yy & 7)) { v |= Hm[yy * words_per_row + c]; ++yy; }
-        while (yy + 8 <= hi) { v |= G[(yy >> 3) * words_per_row + c]; yy += 8; }
-        while (yy < hi) { v |= Hm[yy * words_per_row + c]; ++yy; }
-        a += __popc(v);
+    for (int t = tid; t < ((rows_out + 7) >> 3) * words_per_row; t += blockDim.x) {
+        const int k = t / words_per_row, c = t - k * words_per_row;
+        if (m == 0) {                                        // windows shorter than a group: row by row
+            for (int j = 0; j < 8 && 8 * k + j < rows_out; ++j) {
+                unsigned int v = 0;
+                for (int yy = 8 * k + j; yy < 8 * k + j + e; ++yy) v |= Hm[yy * words_per_row + c];
+                a += __popc(v);
+            }
+            continue;
+        }
+        unsigned int suf[8];
+        unsigned int acc = 0;
+#pragma unroll
+        for (int j = 7; j >= 0; --j) {
+            const int yy = 8 * k + j;
+            if (yy < nh) acc |= Hm[yy * words_per_row + c];
+            suf[j] = acc;
+        }
+        unsigned int common = 0;
+        for (int g = k + 1; g < k + m; ++g) common |= G[g * words_per_row + c];   // g < ng: 8 g + 7 < 8 k + 2 h <= nh
+        const int tail0 = 8 * (k + m);
+        unsigned int pre = 0;
+        for (int i = 0; i < e; ++i) if (tail0 + i < nh) pre |= Hm[(tail0 + i) * words_per_row + c];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if (8 * k + j < rows_out) a += __popc(suf[j] | common | pre);
+            const int yy = tail0 + e + j;
+            if (yy < nh) pre |= Hm[yy * words_per_row + c];
+        }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o);
