@@ -443,8 +443,7 @@ static int launch_score(pose_amd_ctx *ctx, const lane_io &io, int nslots, const 
         int rc;
         const int ntiles = cdiv(ctx->n, 32);
         if ((rc = ensure_feat(ctx, io.stream))) return rc;
-        // the slot list is allocated in whole blocks: the scoring kernel reads it ahead of the count
-        if ((rc = ensure(ctx, *io.vlist, (size_t)cdiv(nslots, MS_POSES) * MS_POSES * 4))) return rc;
+        if ((rc = ensure(ctx, *io.vlist, (size_t)nslots * 4))) return rc;
         if (!io.vcount->p) {
             // {valid poses, blocks done}: zeroed once, the scoring kernel's last block re-arms it
             if ((rc = ensure(ctx, *io.vcount, 8))) return rc;

@@ -230,26 +230,26 @@ __global__ __launch_bounds__(MS_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
     static_assert(MS_POSES == MS_THREADS, "one slot-list entry per thread");
     const int first = blockIdx.x * MS_POSES;
     const int pl0 = wave * (32 * MS_GROUPS) + (lane & 31);    // the lane's pose of group 0; group g: + 32 g
-    // The slot list is read ahead of the valid count (it is allocated in whole blocks), so that
-    // the two loads and the pose loads that depend on them are one round trip shorter.
-    const int lslot = vlist[first + tid];
-    int myslot[MS_GROUPS];
-#pragma unroll
-    for (int g = 0; g < MS_GROUPS; ++g) myslot[g] = vlist[first + pl0 + 32 * g];
     const int nvalid = (int)*nvalid_p;
-    // nvalid_p[1] counts the blocks that are done; the last one zeroes both words for the next
-    // launch on this stream (every block has read the count by then)
+    // The grid covers all slots, valid or not: most blocks of a launch with few valid poses
+    // leave here, before they have asked memory for anything else.
+    if (first >= nvalid) return;
+    // nvalid_p[1] counts the blocks with poses that are done; the last one zeroes both words for
+    // the next launch on this stream (every block has read the count by then)
     auto leave = [&]() {
-        if (tid == 0 && atomicAdd(&nvalid_p[1], 1u) == gridDim.x * gridDim.y - 1) {
+        const unsigned working = (unsigned)((nvalid + MS_POSES - 1) / MS_POSES) * gridDim.y;
+        if (tid == 0 && atomicAdd(&nvalid_p[1], 1u) == working - 1) {
             __hip_atomic_store(&nvalid_p[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(&nvalid_p[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     };
-    if (first >= nvalid) { leave(); return; }            // whole blocks leave together
     const int nblk = min(MS_POSES, nvalid - first);
+    int myslot[MS_GROUPS];
+#pragma unroll
+    for (int g = 0; g < MS_GROUPS; ++g) myslot[g] = pl0 + 32 * g < nblk ? vlist[first + pl0 + 32 * g] : 0;
     s_cnt[tid] = 0;
     s_dense[tid] = 0x7fffffff;
-    s_slot[tid] = tid < nblk ? lslot : -1;
+    s_slot[tid] = tid < nblk ? vlist[first + tid] : -1;
     // blockIdx.y selects the block's share of the correspondences (small launches are spread over
     // the chip that way; the counts of a pose are then added up from several blocks)
     const int tile_begin = (int)blockIdx.y * tiles_per_block;
@@ -263,7 +263,7 @@ __global__ __launch_bounds__(MS_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
 #pragma unroll
     for (int g = 0; g < MS_GROUPS; ++g) {
         const int pl = pl0 + 32 * g;
-        ms_prepare(proj, pl < nblk ? myslot[g] : 0, pl < nblk, q, qc, eps, upper, ops[g]);
+        ms_prepare(proj, myslot[g], pl < nblk, q, qc, eps, upper, ops[g]);
     }
     __syncthreads();
     // eps rounded up and widened for the float32 evaluation of eps |pz| + c
