@@ -56,6 +56,7 @@ struct pose_amd_ctx {
     void *qstage = nullptr;        // pinned staging copy of the same, so that a query is one host-to-device copy
     size_t qstage_cap = 0;
     bool sel_armed = false;        // sel[0..2] hold the initial values of a selection
+    bool sel_fused = false;        // the last scoring launch of the chunk also did the inlier-count selection
     bool timing = true;            // record per-kernel timing events (off for the batch entry point's worker contexts:
                                    // every event is one more command for the GPU's command processor)
     // batch entry point: child contexts (one stream each) and their pinned result words
@@ -431,8 +432,9 @@ static int ensure_feat(pose_amd_ctx *ctx, hipStream_t stream)
 }
 
 static int launch_score(pose_amd_ctx *ctx, const lane_io &io, int nslots, const double *proj_dev, const int *nsol_dev, int maxsol, double eps,
-                        int *counts_dev, unsigned long long *mask_dev, int words_per_pose, bool projf_ready = false)
+                        int *counts_dev, unsigned long long *mask_dev, int words_per_pose, bool projf_ready = false, bool fuse_select = false)
 {
+    ctx->sel_fused = false;
     const query_dev q = make_query(ctx);
     // slots per block: as many as possible (each block streams the correspondences once for all
     // its poses) while small launches still get about four blocks per compute unit
@@ -458,7 +460,9 @@ static int launch_score(pose_amd_ctx *ctx, const lane_io &io, int nslots, const 
         hipLaunchKernelGGL(k_compact_valid, dim3(cdiv(nslots, MS_COMPACT_SLOTS)), dim3(256), 0, io.stream, nslots, nsol_dev, maxsol, (int *)io.vlist->p,
                            (unsigned int *)io.vcount->p, counts_dev, gy > 1 ? 1 : 0);
         hipLaunchKernelGGL(k_score_mfma, dim3(pose_batches, gy), dim3(MS_THREADS), 0, io.stream, q, ctx->centre, (const uint4 *)ctx->feat.p,
-                           ntiles, tpb, proj_dev, (const int *)io.vlist->p, (unsigned int *)io.vcount->p, eps, counts_dev);
+                           ntiles, tpb, proj_dev, (const int *)io.vlist->p, (unsigned int *)io.vcount->p, eps, counts_dev,
+                           fuse_select && gy == 1 ? (unsigned long long *)ctx->sel.p : nullptr);
+        ctx->sel_fused = fuse_select && gy == 1;
         HIPCHK(ctx, hipGetLastError());
         return POSE_AMD_OK;
     }
@@ -623,7 +627,7 @@ int pose_amd_set_samples(pose_amd_ctx *ctx, const uint32_t *samples, uint32_t hy
 // Selection over the first `limit` slots of the chunk.  out[0..2] = best key, first slot reaching
 // `thresh`, valid slots; best[0..12] = pose record and best[13..24] = projection matrix of the best
 // slot (unchanged when there is no valid slot).  One download for everything.
-static int run_select(pose_amd_ctx *ctx, int limit, int maxsol, unsigned thresh, unsigned long long out[3], double best[25])
+static int arm_select(pose_amd_ctx *ctx)
 {
     int rc;
     if ((rc = ensure(ctx, ctx->sel, 31 * 8))) return rc;
@@ -633,11 +637,20 @@ static int run_select(pose_amd_ctx *ctx, int limit, int maxsol, unsigned thresh,
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));      // init is a stack array
         ctx->sel_armed = true;                               // k_gather_best re-arms it after every selection
     }
+    return POSE_AMD_OK;
+}
+
+// `fused`: the scoring kernel of this chunk already left key and valid count in sel (no threshold).
+static int run_select(pose_amd_ctx *ctx, int limit, int maxsol, unsigned thresh, unsigned long long out[3], double best[25], bool fused = false)
+{
+    int rc;
+    if ((rc = arm_select(ctx))) return rc;
     int blocks = cdiv(limit, 256);
     if (blocks > 1024) blocks = 1024;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(k_select, dim3(blocks), dim3(256), 0, ctx->stream, limit, (const int *)ctx->counts.p, (const int *)ctx->nsol.p,
-                       maxsol, thresh, (unsigned long long *)ctx->sel.p);
+    if (!fused)
+        hipLaunchKernelGGL(k_select, dim3(blocks), dim3(256), 0, ctx->stream, limit, (const int *)ctx->counts.p, (const int *)ctx->nsol.p,
+                           maxsol, thresh, (unsigned long long *)ctx->sel.p);
     hipLaunchKernelGGL(k_gather_best, dim3(1), dim3(64), 0, ctx->stream, (unsigned long long *)ctx->sel.p, (const double *)ctx->pose.p,
                        (const double *)ctx->proj.p);
     HIPCHK(ctx, hipGetLastError());
@@ -650,7 +663,8 @@ static int run_select(pose_amd_ctx *ctx, int limit, int maxsol, unsigned thresh,
 
 // Minimal solves then scoring of every returned pose for the hypotheses [h0, h0+hc) of the
 // current chunk, whose first hypothesis is c0 (pose slots are indexed relative to the chunk).
-static int solve_and_score_on(pose_amd_ctx *ctx, const lane_io &io, uint32_t c0, uint32_t h0, uint32_t hc, int maxsol, double eps)
+static int solve_and_score_on(pose_amd_ctx *ctx, const lane_io &io, uint32_t c0, uint32_t h0, uint32_t hc, int maxsol, double eps,
+                              bool fuse_select = false)
 {
     const query_dev q = make_query(ctx);
     const uint32_t *smp = (const uint32_t *)ctx->samples.p + (size_t)h0 * 4;
@@ -672,19 +686,23 @@ static int solve_and_score_on(pose_amd_ctx *ctx, const lane_io &io, uint32_t c0,
     }
     HIPCHK(ctx, hipGetLastError());
     if (ctx->timing) HIPCHK(ctx, hipEventRecord(io.ev[1], io.stream));
-    if ((rc = launch_score(ctx, io, (int)((size_t)hc * maxsol), proj, nsol, maxsol, eps, counts, nullptr, 0, projf != nullptr))) return rc;
+    if (fuse_select && (rc = arm_select(ctx))) return rc;
+    if ((rc = launch_score(ctx, io, (int)((size_t)hc * maxsol), proj, nsol, maxsol, eps, counts, nullptr, 0, projf != nullptr, fuse_select)))
+        return rc;
     if (ctx->timing) HIPCHK(ctx, hipEventRecord(io.ev[2], io.stream));
     return POSE_AMD_OK;
 }
 
 // One chunk of hypotheses [h0, h0+hc).  A large chunk of a run without early exit is cut in two
 // halves that go to two streams: their kernels stress different pipes and overlap.
-static int solve_and_score(pose_amd_ctx *ctx, uint32_t h0, uint32_t hc, int maxsol, double eps, bool may_split)
+// fuse_select: selection is by inlier count over the whole chunk without a threshold, so the
+// scoring kernel may do it on the way (single-stream chunks only; ctx->sel_fused tells).
+static int solve_and_score(pose_amd_ctx *ctx, uint32_t h0, uint32_t hc, int maxsol, double eps, bool may_split, bool fuse_select)
 {
     int rc;
     const uint32_t ha = ((hc / 2 + 63) / 64) * 64;
     ctx->side_used = may_split && ctx->overlap && ha < hc && use_mfma_screen(ctx, (int)((size_t)std::min(ha, hc - ha) * maxsol), false);
-    if (!ctx->side_used) return solve_and_score_on(ctx, main_io(ctx), h0, h0, hc, maxsol, eps);
+    if (!ctx->side_used) return solve_and_score_on(ctx, main_io(ctx), h0, h0, hc, maxsol, eps, fuse_select);
     if (!ctx->stream2) {
         HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
         for (int i = 0; i < 6; ++i) HIPCHK(ctx, hipEventCreate(&ctx->ev2[i]));
@@ -695,6 +713,7 @@ static int solve_and_score(pose_amd_ctx *ctx, uint32_t h0, uint32_t hc, int maxs
     HIPCHK(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev2[3], 0));
     if ((rc = solve_and_score_on(ctx, main_io(ctx), h0, h0, ha, maxsol, eps))) return rc;
     if ((rc = solve_and_score_on(ctx, side_io(ctx), h0, h0 + ha, hc - ha, maxsol, eps))) return rc;
+    ctx->sel_fused = false;
     HIPCHK(ctx, hipEventRecord(ctx->ev2[5], ctx->stream2));
     HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev2[5], 0));
     return POSE_AMD_OK;
@@ -755,14 +774,14 @@ int pose_amd_ransac_run(pose_amd_ctx *ctx, const pose_amd_params *prm, pose_amd_
         hc = std::min(next_chunk, H - h0);
         next_chunk = std::min(chunk, next_chunk * 4);
         const size_t nslots = (size_t)hc * maxsol;
-        if ((rc = solve_and_score(ctx, h0, hc, maxsol, prm->eps, !prm->early_exit))) return rc;
+        if ((rc = solve_and_score(ctx, h0, hc, maxsol, prm->eps, !prm->early_exit, !prm->early_exit && !coverage))) return rc;
         long long chunk_best = -1;       // slot within the chunk that became the kept pose
         bool have_gathered = false;      // its pose and projection matrix came with the selection's download
         double gathered[25];
         uint32_t chunk_steps = hc;
         if (!coverage) {
             unsigned long long out[3];
-            if ((rc = run_select(ctx, (int)nslots, maxsol, prm->early_exit ? thresh_u : 0xFFFFFFFFu, out, gathered))) return rc;
+            if ((rc = run_select(ctx, (int)nslots, maxsol, prm->early_exit ? thresh_u : 0xFFFFFFFFu, out, gathered, ctx->sel_fused))) return rc;
             if (prm->early_exit && out[1] != ~0ull) {
                 chunk_steps = (uint32_t)(out[1] / maxsol) + 1;
                 done = true;

@@ -218,7 +218,8 @@ __device__ __forceinline__ bool ms_exact_inlier(const query_dev &q, const double
 // group's result overlaps the second group's products.
 __global__ __launch_bounds__(MS_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_score_mfma(
     query_dev q, query_centre qc, const uint4 *__restrict__ feat, int ntiles, int tiles_per_block, const double *__restrict__ proj,
-    const int *__restrict__ vlist, unsigned int *__restrict__ nvalid_p, double eps, int *__restrict__ counts)
+    const int *__restrict__ vlist, unsigned int *__restrict__ nvalid_p, double eps, int *__restrict__ counts,
+    unsigned long long *__restrict__ sel)
 {
     __shared__ uint4 s_feat[MS_CHUNK_TILES * MS_TILE_BYTES / 16];
     __shared__ int s_cnt[MS_POSES];
@@ -392,6 +393,21 @@ __global__ __launch_bounds__(MS_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
     __syncthreads();
     if (gridDim.y == 1) {
         for (int i = tid; i < nblk; i += MS_THREADS) counts[s_slot[i]] = s_cnt[i];
+        if (sel) {
+            // selection by inlier count folded in: the block's best (count, lowest slot) key and
+            // its number of poses go where the selection kernel would put them
+            unsigned long long key = tid < nblk ? ((unsigned long long)(unsigned)s_cnt[tid] << 32) | (0xFFFFFFFFu - (unsigned)s_slot[tid]) : 0ull;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { const unsigned long long k2 = __shfl_xor(key, o); key = k2 > key ? k2 : key; }
+            unsigned long long *s_key = reinterpret_cast<unsigned long long *>(s_feat);   // the chunk buffer is free by now
+            if (lane == 0) s_key[wave] = key;
+            __syncthreads();
+            if (tid == 0) {
+                for (int w = 1; w < MS_WAVES; ++w) key = s_key[w] > key ? s_key[w] : key;
+                atomicMax(&sel[0], key);
+                atomicAdd(&sel[2], (unsigned long long)nblk);
+            }
+        }
     } else {
         for (int i = tid; i < nblk; i += MS_THREADS) if (s_cnt[i]) atomicAdd(&counts[s_slot[i]], s_cnt[i]);
     }

@@ -564,6 +564,33 @@ def test_two_stream_split_gives_the_same_run(ctx):
             assert np.array_equal(a["C"], b["C"]) and np.array_equal(a["Rc"], b["Rc"]) and a["focal"] == b["focal"]
 
 
+def test_selection_inside_the_scoring_kernel_equals_the_selection_kernel(ctx):
+    """A large fixed-budget chunk selected by inlier count gets its selection from the matrix-core
+    scoring kernel; a context that scores with the packed kernel runs the selection kernel.  Best
+    hypothesis (lowest slot among equal counts: few matches give many ties), counts and the number
+    of scored poses must agree."""
+    from pose_estimation_amd import Context
+    os.environ["POSE_AMD_SCORE"] = "packed"
+    try:
+        ref_ctx = Context(0)
+    finally:
+        del os.environ["POSE_AMD_SCORE"]
+    with ref_ctx:
+        for known, n, frac, H in ((False, 2000, 0.2, 1 << 17), (True, 40, 0.5, 1 << 18), (False, 33, 0.0, 1 << 17)):
+            q = synth.make_query(n, frac, 77 + n, known_focal=known)
+            res = []
+            for c in (ctx, ref_ctx):
+                upload(c, q)
+                c.sample(SAMPLE_BASIC, 9, 1, 0, H, export=False)
+                res.append(c.ransac_run(SELECT_INLIERS, 0.5, early_exit=False, hyp_count=H, want_per_hyp=True))
+            a, b = res
+            assert np.array_equal(a["nsol"], b["nsol"]) and np.array_equal(a["counts"], b["counts"])
+            for k in ("found", "best_hyp", "best_sol", "inliers", "steps", "poses_scored"):
+                assert a[k] == b[k], k
+            if a["found"]:
+                assert np.array_equal(a["C"], b["C"]) and np.array_equal(a["Rc"], b["Rc"]) and a["focal"] == b["focal"]
+
+
 def test_ransac_large_query_config5_shape(ctx):
     """BASELINE config 5 in miniature: 100 000 matches, 1 % inliers, a hypothesis range split in
     two halves whose packed keys are max-reduced (what the ranks do) equals the whole range."""
