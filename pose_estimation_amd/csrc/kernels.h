@@ -226,7 +226,7 @@ __device__ __forceinline__ void load_obs(const query_dev &q, uint32_t idx, doubl
 }
 
 // P3P branch of the RANSAC step (query_processor_basic.cpp:228-291): one hypothesis per lane.
-__global__ void k_solve_p3p(query_dev q, uint32_t hyp_count, const uint32_t *__restrict__ samples, double *__restrict__ proj,
+__global__ __launch_bounds__(64) void k_solve_p3p(query_dev q, uint32_t hyp_count, const uint32_t *__restrict__ samples, double *__restrict__ proj,
                             double *__restrict__ pose, int *__restrict__ nsol, float *__restrict__ projf, double eps)
 {
     const uint32_t h = blockIdx.x * blockDim.x + threadIdx.x;
