@@ -73,16 +73,25 @@ __device__ __forceinline__ uint32_t draw_at(uint64_t seed, uint32_t query_id, ui
     return buf[pos & 3u];
 }
 
+//
+// BITMAP: camera ids are small enough (below 32 bm_words) for the running intersection to be
+// kept as a bitmap in LDS as well.  A candidate's overlap with it is then a sum of independent
+// bit tests instead of a merge of two sorted lists whose every step waits for the one before
+// (the slowest lane's merge sets the pace of a round), and the whole wave rebuilds the
+// intersection when a pick is accepted.  The sets are the same, so are the tuples.
+template <bool BITMAP>
 __global__ __launch_bounds__(64 * SAMPLE_ADV_WAVES) void k_sample_advanced(query_dev q, int m, uint64_t seed, uint32_t query_id,
                                                                             uint32_t hyp_begin, uint32_t hyp_count,
                                                                             const double *__restrict__ gain, uint32_t *__restrict__ samples,
-                                                                            int *__restrict__ status)
+                                                                            int *__restrict__ status, int bm_words)
 {
     __shared__ uint32_t s_inter[SAMPLE_ADV_WAVES][MAXCAM];
+    extern __shared__ uint32_t s_cam_bits[];             // BITMAP: bm_words words per wave
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint32_t t = blockIdx.x * SAMPLE_ADV_WAVES + wave;
     if (t >= hyp_count) return;                          // whole waves leave together
     uint32_t *inter = s_inter[wave];
+    uint32_t *bm = s_cam_bits + (BITMAP ? wave * bm_words : 0);
     const uint32_t hyp = hyp_begin + t;
     const unsigned long long lt = (1ull << lane) - 1ull;  // lanes before this one
     uint32_t di = 0, dp = 0;                             // draws consumed from the index / probability streams
@@ -108,10 +117,20 @@ __global__ __launch_bounds__(64 * SAMPLE_ADV_WAVES) void k_sample_advanced(query
             bool dup = false;
             for (int j = 0; j < nsel; ++j) dup = dup || lsel[j] == l;
             if (!dup) {
-                uint32_t p = cb, r = 0;
-                while (p < ce && r < ninter) {
-                    const uint32_t a = q.cam_ids[p], b = inter[r];
-                    if (a < b) ++p; else if (b < a) ++r; else { ++ncheck; ++p; ++r; }
+                if constexpr (BITMAP) {
+                    for (uint32_t p = cb; p < ce; p += 4) {
+                        uint32_t a[4];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) a[k] = q.cam_ids[min(p + (uint32_t)k, ce - 1u)];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) ncheck += p + (uint32_t)k < ce ? (bm[a[k] >> 5] >> (a[k] & 31u)) & 1u : 0u;
+                    }
+                } else {
+                    uint32_t p = cb, r = 0;
+                    while (p < ce && r < ninter) {
+                        const uint32_t a = q.cam_ids[p], b = inter[r];
+                        if (a < b) ++p; else if (b < a) ++r; else { ++ncheck; ++p; ++r; }
+                    }
                 }
             }
             const bool empty = !dup && ncheck == 0 && zero_check_count <= zero_check_limit;   // zero_check++ (:383-386)
@@ -150,6 +169,18 @@ __global__ __launch_bounds__(64 * SAMPLE_ADV_WAVES) void k_sample_advanced(query
         if (i == 0) {
             ninter = ace - acb;
             for (uint32_t c = lane; c < ninter; c += 64) inter[c] = q.cam_ids[acb + c];
+        } else if constexpr (BITMAP) {
+            // the accepted candidate's cameras that are in the bitmap, in order, by the whole wave
+            uint32_t w = 0;
+            for (uint32_t base = acb; base < ace; base += 64) {
+                const uint32_t p = base + (uint32_t)lane;
+                const uint32_t a = p < ace ? q.cam_ids[p] : 0u;
+                const bool keep = p < ace && ((bm[a >> 5] >> (a & 31u)) & 1u);
+                const unsigned long long bk = __ballot(keep);
+                if (keep) inter[w + (uint32_t)__popcll(bk & lt)] = a;
+                w += (uint32_t)__popcll(bk);
+            }
+            ninter = w;
         } else {
             if (lane == ev) {
                 uint32_t p = cb, r = 0, w = 0;
@@ -162,6 +193,15 @@ __global__ __launch_bounds__(64 * SAMPLE_ADV_WAVES) void k_sample_advanced(query
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
+        if constexpr (BITMAP) {
+            // the bitmap of the new intersection
+            for (int c = lane; c < bm_words; c += 64) bm[c] = 0u;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            for (uint32_t c = lane; c < ninter; c += 64) atomicOr(&bm[inter[c] >> 5], 1u << (inter[c] & 31u));
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
         sel[nsel] = aidx; lsel[nsel] = lindex_of(q, aidx); ++nsel;
         ++i; zero_check = 0;
     }
@@ -435,7 +475,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 }
 
 // Raw batched solver kernels for the parity entry points (inputs straight from the caller).
-__global__ void k_p3p_batch(int count, const double *__restrict__ fcols, const double *__restrict__ pcols, double *__restrict__ sol,
+__global__ __launch_bounds__(64) void k_p3p_batch(int count, const double *__restrict__ fcols, const double *__restrict__ pcols, double *__restrict__ sol,
                             int *__restrict__ status)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;

@@ -55,6 +55,7 @@ struct pose_amd_ctx {
     dev_buf qpack;                 // the query's five (six) arrays in one allocation; kx .. lindex point into it
     void *qstage = nullptr;        // pinned staging copy of the same, so that a query is one host-to-device copy
     size_t qstage_cap = 0;
+    uint32_t cam_max = 0;          // largest camera id of the current camera sets
     bool sel_armed = false;        // sel[0..2] hold the initial values of a selection
     bool sel_fused = false;        // the last scoring launch of the chunk also did the inlier-count selection
     bool timing = true;            // record per-kernel timing events (off for the batch entry point's worker contexts:
@@ -371,8 +372,10 @@ int pose_amd_set_camsets(pose_amd_ctx *ctx, const uint32_t *cam_off, const uint3
 {
     if (!ctx || !cam_off || ctx->n <= 0) return fail(ctx, POSE_AMD_EINVAL, "set_camsets: no query or bad argument");
     bool any5 = false;
+    uint32_t cam_max = 0;
     for (int i = 0; i < ctx->n; ++i) {
         if (cam_off[i + 1] < cam_off[i]) return fail(ctx, POSE_AMD_EINVAL, "set_camsets: offsets must be non-decreasing");
+        if (cam_off[i + 1] > cam_off[i]) cam_max = std::max(cam_max, cam_ids[cam_off[i + 1] - 1]);   // ascending: the last is the largest
         const uint32_t sz = cam_off[i + 1] - cam_off[i];
         if (sz > (uint32_t)MAXCAM) return fail(ctx, POSE_AMD_EINVAL, "set_camsets: a camera set exceeds 128 entries");
         any5 |= sz >= 5;
@@ -388,6 +391,7 @@ int pose_amd_set_camsets(pose_amd_ctx *ctx, const uint32_t *cam_off, const uint3
     const size_t total = cam_off[ctx->n];
     if ((rc = upload(ctx, ctx->cam_ids, cam_ids, (total ? total : 1) * 4))) return rc;
     ctx->has_cam = true;
+    ctx->cam_max = cam_max;
     return pose_amd_synchronize(ctx);
 }
 
@@ -597,8 +601,16 @@ int pose_amd_sample(pose_amd_ctx *ctx, int sample_mode, uint64_t seed, uint32_t 
                            hyp_count, (uint32_t *)ctx->samples.p);
     } else {
         if ((rc = ensure(ctx, ctx->sample_status, (size_t)hyp_count * 4))) return rc;
-        hipLaunchKernelGGL(k_sample_advanced, dim3(cdiv(hyp_count, SAMPLE_ADV_WAVES)), dim3(64 * SAMPLE_ADV_WAVES), 0, ctx->stream, q, m, seed, query_id, hyp_begin,
-                           hyp_count, (const double *)ctx->gain.p, (uint32_t *)ctx->samples.p, (int *)ctx->sample_status.p);
+        // camera ids below 65536: the running intersection is also kept as a bitmap (8 KB per wave at most)
+        const int bm_words = ctx->cam_max < 65536u ? (int)(ctx->cam_max / 32u) + 1 : 0;
+        if (bm_words)
+            hipLaunchKernelGGL(k_sample_advanced<true>, dim3(cdiv(hyp_count, SAMPLE_ADV_WAVES)), dim3(64 * SAMPLE_ADV_WAVES),
+                               (size_t)SAMPLE_ADV_WAVES * bm_words * 4, ctx->stream, q, m, seed, query_id, hyp_begin, hyp_count,
+                               (const double *)ctx->gain.p, (uint32_t *)ctx->samples.p, (int *)ctx->sample_status.p, bm_words);
+        else
+            hipLaunchKernelGGL(k_sample_advanced<false>, dim3(cdiv(hyp_count, SAMPLE_ADV_WAVES)), dim3(64 * SAMPLE_ADV_WAVES), 0, ctx->stream, q, m,
+                               seed, query_id, hyp_begin, hyp_count, (const double *)ctx->gain.p, (uint32_t *)ctx->samples.p,
+                               (int *)ctx->sample_status.p, 0);
     }
     HIPCHK(ctx, hipGetLastError());
     if (samples_out && (rc = download(ctx, samples_out, ctx->samples.p, (size_t)hyp_count * 16))) return rc;

@@ -289,6 +289,27 @@ def test_advanced_samples_bit_exact(ctx):
     for h in range(300):
         exp, k, kp = O.sample_advanced(77, 3, h, 4, 600, q["cam_off"], q["cam_ids"])
         assert np.array_equal(got[h], exp), h
+    # camera ids too large for the kernel that keeps the running intersection as a bitmap, and
+    # large sets (long merges): same tuples from the list-merging kernel
+    big = (q["cam_ids"] + np.uint32(100000)).astype(np.uint32)
+    ctx.set_camsets(q["cam_off"], big)
+    assert np.array_equal(ctx.sample(SAMPLE_ADVANCED, 77, 3, 0, 300), got)
+    q2 = synth.add_camsets(synth.make_query(400, 0.5, 10), 11, n_cams=300, cluster=100)
+    rng = np.random.default_rng(5)
+    off, ids = [0], []
+    for i in range(400):                                   # 20-128 cameras per point
+        k = int(rng.integers(20, 129))
+        ids.append(np.sort(rng.choice(300, k, replace=False)).astype(np.uint32))
+        off.append(off[-1] + k)
+    q2["cam_off"], q2["cam_ids"] = np.array(off, np.uint32), np.concatenate(ids)
+    upload(ctx, q2)
+    for shift in (0, 70000):
+        ci = (q2["cam_ids"] + np.uint32(shift)).astype(np.uint32)
+        ctx.set_camsets(q2["cam_off"], ci)
+        got2 = ctx.sample(SAMPLE_ADVANCED, 5, 1, 0, 64)
+        for h in range(64):
+            exp, k, kp = O.sample_advanced(5, 1, h, 4, 400, q2["cam_off"], ci)
+            assert np.array_equal(got2[h], exp), (shift, h)
 
 
 def test_sampler_rejects_bad_input(ctx):
