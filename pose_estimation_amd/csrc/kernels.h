@@ -161,7 +161,14 @@ __global__ __launch_bounds__(64 * SAMPLE_ADV_WAVES) void k_sample_advanced(query
         di += (uint32_t)ev + 1;
         if (restart) {
             i = 0; nsel = 0; ninter = 0; zero_check = 0; zero_check_count++;
-            continue;
+            // The candidates drawn after the restarting one are candidates for the first pick of
+            // the new tuple (index draws only, :350-359): take it from this round if it is there.
+            const unsigned long long after = ev == 63 ? 0ull : ~((2ull << ev) - 1ull);
+            const unsigned long long ok = __ballot(ce - cb >= 5) & after;
+            if (!ok) { di += 63u - (uint32_t)ev; continue; }
+            const int ev2 = __builtin_ctzll(ok);
+            di += (uint32_t)(ev2 - ev);
+            ev = ev2;
         }
         // the accepted candidate becomes pick i; the running intersection becomes its check set
         const uint32_t aidx = (uint32_t)__builtin_amdgcn_readlane((int)idx, ev);
