@@ -129,7 +129,7 @@ def main():
         hyps_rank = H * args.steps
         # large launches are scored by the matrix-core screen, small ones by the packed-float32 one
         maxsol = 4 if args.known_focal else 10
-        score_kernel = ("k_score_mfma" if hyps_rank // launches * maxsol >= 131072 and
+        score_kernel = ("k_score_mfma" if hyps_rank // launches * maxsol >= int(os.environ.get("POSE_AMD_MFMA_MIN_SLOTS", "8192")) and
                         os.environ.get("POSE_AMD_SCORE") not in ("packed", "fp64") else "k_score_screen")
         work = {"k_solve_p3p": (tim["solve_ms"], hyps_rank * P3P_FLOP_PER_HYP)} if args.known_focal else {}
         work.update({"k_p4pf_elim": (tim["elim_ms"], hyps_rank * ELIM_FLOP_PER_HYP),
@@ -144,6 +144,11 @@ def main():
                     "kernel_ms_per_step": {k: round(v / args.steps, 3) for k, v in tim.items() if k.endswith("_ms")},
                     "kernel_tflops": {k: round(f / (ms * 1e-3) / 1e12, 3) for k, (ms, f) in work.items() if ms > 0},
                     "poses_per_hypothesis": round(poses / hyps_rank, 3)}
+        # the same kernel against the HBM roof (recorded HBM bytes per launch over the live duration):
+        # it is far from it, which is why the bound is stated as float64 vector arithmetic
+        if roofline["traffic"] and dom_ms > 0:
+            gbps = roofline["traffic"] / (dom_ms / launches * 1e-3) / 1e9
+            roofline["hbm"] = {"achieved": round(gbps, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(gbps / 8000.0, 4)}
         out = {"metric": "RANSAC hypotheses/sec (%s solve+score)" % ("P3P" if args.known_focal else "P4Pf"), "value": round(total_hyps / dt, 1), "unit": "hypotheses/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
