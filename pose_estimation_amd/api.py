@@ -33,6 +33,18 @@ def _ptr(a, t):
     return None if a is None else a.ctypes.data_as(t)
 
 
+class PreparedBatch:
+    """Query descriptors of a batch in the library's layout (see Context.prepare_batch)."""
+    def __init__(self, nq, descs, keep):
+        self.nq, self.descs, self._keep = nq, descs, keep
+
+
+def result_dict(r):
+    return dict(found=r.found, focal=r.focal, C=np.array(r.C[:]), Rc=np.array(r.Rc[:]).reshape(3, 3), inliers=r.inliers,
+                area_fit=r.area_fit, area_all=r.area_all, steps=r.steps, best_hyp=r.best_hyp, best_sol=r.best_sol,
+                poses_scored=r.poses_scored)
+
+
 class Context:
     """One GPU, one stream.  Not thread-safe (one host thread per GPU)."""
 
@@ -180,12 +192,9 @@ class Context:
             out["nsol"], out["counts"] = nsol, counts
         return out
 
-    def ransac_batch(self, queries, sample_mode=SAMPLE_BASIC, seed=0, budget=10000, select_mode=SELECT_COVERAGE, eps=0.5,
-                     early_exit=True, inlier_divisor=10, inlier_absolute=12):
-        """Process for many independent queries in one call.  `queries`: dicts with kx, ky, X, Y, Z,
-        width, height, focal (0 = unknown) and optionally lindex, cam_off, cam_ids, query_id
-        (default: position in the list).  Returns one result dict per query, equal to what
-        set_query + sample(sample_mode, seed, query_id, 0, budget) + ransac_run give."""
+    def prepare_batch(self, queries):
+        """Descriptor array for ransac_batch, built once for query lists that are processed more
+        than once (it keeps the arrays it points to alive)."""
         from ._lib import QueryDesc
         nq = len(queries)
         descs = (QueryDesc * max(nq, 1))()
@@ -202,13 +211,25 @@ class Context:
             d.lindex, d.cam_off, d.cam_ids = _ptr(li, _lib._up), _ptr(co, _lib._up), _ptr(ci, _lib._up)
             d.width, d.height, d.focal = int(q["width"]), int(q["height"]), float(q["focal"])
             d.query_id = int(q.get("query_id", i))
+        return PreparedBatch(nq, descs, keep)
+
+    def ransac_batch(self, queries, sample_mode=SAMPLE_BASIC, seed=0, budget=10000, select_mode=SELECT_COVERAGE, eps=0.5,
+                     early_exit=True, inlier_divisor=10, inlier_absolute=12, raw=False):
+        """Process for many independent queries in one call.  `queries`: dicts with kx, ky, X, Y, Z,
+        width, height, focal (0 = unknown) and optionally lindex, cam_off, cam_ids, query_id
+        (default: position in the list), or what prepare_batch made of such a list.  Returns one
+        result dict per query, equal to what set_query + sample(sample_mode, seed, query_id, 0,
+        budget) + ransac_run give; with raw=True the array of result records as the library
+        filled it (fields as in the dicts), without the per-query conversion."""
+        prep = queries if isinstance(queries, PreparedBatch) else self.prepare_batch(queries)
+        nq = prep.nq
         prm = Params(int(select_mode), float(eps), int(bool(early_exit)), int(inlier_divisor), int(inlier_absolute))
         res = (Result * max(nq, 1))()
-        self._chk(self._lib.pose_amd_ransac_batch(self._h, nq, descs, int(sample_mode), int(seed), int(budget), C.byref(prm), res),
+        self._chk(self._lib.pose_amd_ransac_batch(self._h, nq, prep.descs, int(sample_mode), int(seed), int(budget), C.byref(prm), res),
                   "ransac_batch")
-        return [dict(found=r.found, focal=r.focal, C=np.array(r.C[:]), Rc=np.array(r.Rc[:]).reshape(3, 3), inliers=r.inliers,
-                     area_fit=r.area_fit, area_all=r.area_all, steps=r.steps, best_hyp=r.best_hyp, best_sol=r.best_sol,
-                     poses_scored=r.poses_scored) for r in res[:nq]]
+        if raw:
+            return res
+        return [result_dict(r) for r in res[:nq]]
 
     def best_mask(self):
         m = np.zeros(self.n, dtype=np.uint8)

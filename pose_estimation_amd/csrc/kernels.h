@@ -809,8 +809,9 @@ __global__ __launch_bounds__(SCORE_THREADS) __attribute__((amdgpu_waves_per_eu(6
 // Coverage area (query_processor.cpp:126-169): the number of pixels covered by the clamped
 // coverage boxes of a pose's inliers.  all_matches != 0 takes every correspondence (the
 // match_area map).  With `slots` the i-th pose is proj[slots[i]] (candidates picked out of a
-// chunk).  blockIdx.y selects a band of `band_rows` image rows; the band sums are added up in
-// areas[pose] (zeroed by the host beforehand).  Nothing but the sums leaves the chip.
+// chunk).  blockIdx.y selects a band of `band_rows` image rows; every block writes the sum of its
+// band to band_sums[pose * gridDim.y + band] (no zeroing, no atomics: the host adds the bands
+// up).  Nothing but the sums leaves the chip.
 //
 // All boxes have the same half width h = ceil(width / 20) / 2 in both directions, and a box is
 // the product of a column interval that depends on x only and a row interval that depends on
@@ -828,7 +829,7 @@ __global__ __launch_bounds__(SCORE_THREADS) __attribute__((amdgpu_waves_per_eu(6
 constexpr int COV_UNROLL = 8;
 __global__ __launch_bounds__(256) void k_coverage(query_dev q, int nposes, const double *__restrict__ proj, const int *__restrict__ slots,
                                                   double eps, int all_matches, int band_rows, int words_per_row,
-                                                  unsigned long long *__restrict__ areas)
+                                                  unsigned long long *__restrict__ band_sums)
 {
     extern __shared__ unsigned int s_bm[];                   // nh painted rows, then ng rows of group unions
     __shared__ unsigned long long s_sum[4];
@@ -836,9 +837,10 @@ __global__ __launch_bounds__(256) void k_coverage(query_dev q, int nposes, const
     const int pose = blockIdx.x;
     if (pose >= nposes) return;
     const int tid = threadIdx.x;
+    unsigned long long *out = band_sums + (size_t)pose * gridDim.y + blockIdx.y;
     const int row0 = blockIdx.y * band_rows, row1 = min(q.height, row0 + band_rows);
     const int cover = (int)ceilf((float)q.width / 20.0f), h = cover / 2;
-    if (h == 0) return;                                      // every box is empty
+    if (h == 0) { if (tid == 0) *out = 0ull; return; }       // every box is empty
     const int nh = (row1 - row0) + 2 * h - 1;                // keypoint rows y_base .. y_base + nh - 1 reach into the band
     const int ng = (nh + 7) >> 3;
     const int y_base = row0 - h + 1;
@@ -887,7 +889,7 @@ __global__ __launch_bounds__(256) void k_coverage(query_dev q, int nposes, const
         }
     }
     __syncthreads();
-    if (!s_any) return;                                      // no inlier near this band
+    if (!s_any) { if (tid == 0) *out = 0ull; return; }       // no inlier near this band
     for (int t = tid; t < ng * words_per_row; t += blockDim.x) {
         const int g = t / words_per_row, c = t - g * words_per_row;
         unsigned int v = 0;
@@ -936,15 +938,12 @@ __global__ __launch_bounds__(256) void k_coverage(query_dev q, int nposes, const
     for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o);
     if ((tid & 63) == 0) s_sum[tid >> 6] = a;
     __syncthreads();
-    if (tid == 0) {
-        const unsigned long long sum = s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3];
-        if (sum) atomicAdd(&areas[pose], sum);
-    }
+    if (tid == 0) *out = s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3];
 }
 
 __global__ __launch_bounds__(256) void k_coverage_direct(query_dev q, int nposes, const double *__restrict__ proj, const int *__restrict__ slots,
                                                   double eps, int all_matches, int band_rows, int words_per_row,
-                                                  unsigned long long *__restrict__ areas)
+                                                  unsigned long long *__restrict__ band_sums)
 {
     extern __shared__ unsigned int s_bm[];
     __shared__ unsigned long long s_sum[256];
@@ -1004,7 +1003,7 @@ __global__ __launch_bounds__(256) void k_coverage_direct(query_dev q, int nposes
     s_sum[tid] = a;
     __syncthreads();
     for (int o = 128; o > 0; o >>= 1) { if (tid < o) s_sum[tid] += s_sum[tid + o]; __syncthreads(); }
-    if (tid == 0 && s_sum[0]) atomicAdd(&areas[pose], s_sum[0]);
+    if (tid == 0) band_sums[(size_t)pose * gridDim.y + blockIdx.y] = s_sum[0];
 }
 
 // ------------------------------------------------------------------------------------------

@@ -56,6 +56,7 @@ struct pose_amd_ctx {
     void *qstage = nullptr;        // pinned staging copy of the same, so that a query is one host-to-device copy
     size_t qstage_cap = 0;
     uint32_t cam_max = 0;          // largest camera id of the current camera sets
+    std::vector<unsigned long long> band_host;   // per-band coverage sums as downloaded
     bool sel_armed = false;        // sel[0..2] hold the initial values of a selection
     bool sel_fused = false;        // the last scoring launch of the chunk also did the inlier-count selection
     bool timing = true;            // record per-kernel timing events (off for the batch entry point's worker contexts:
@@ -524,13 +525,13 @@ static int coverage_dev(pose_amd_ctx *ctx, int nposes, const double *proj_dev, d
     const query_dev q = make_query(ctx);
     const int wpr = (ctx->width + 31) / 32;
     int rc;
-    if ((rc = ensure(ctx, ctx->areas, (size_t)nposes * 8))) return rc;
-    HIPCHK(ctx, hipMemsetAsync(ctx->areas.p, 0, (size_t)nposes * 8, ctx->stream));
     // Bands of image rows.  A band of R rows needs R + 2h - 1 painted rows (h: half box width) plus
     // one row of unions per eight of them in LDS, 64 KB at most; thinner bands when few poses are
     // evaluated, so that about 2 000 blocks exist and a single pose (the all-matches map) is not
     // left to a handful of them.  Images too wide for that (the 2h extra rows alone exceed the
     // LDS) take the kernel that paints whole boxes into a band bitmap of at most 48 KB.
+    // Every block writes the sum of its band; the bands of a pose are added up here, so the
+    // device side needs neither zeroed sums nor atomics.
     if ((size_t)wpr * 4 > 48 * 1024) return fail(ctx, POSE_AMD_EINVAL, "coverage: image wider than 393216 px");
     const int half = (int)std::ceil((float)ctx->width / 20.0f) / 2;
     const int lds_rows = (64 * 1024) / (wpr * 4);                       // rows of words_per_row words in 64 KB
@@ -538,26 +539,47 @@ static int coverage_dev(pose_amd_ctx *ctx, int nposes, const double *proj_dev, d
     const bool separable = sep_rows >= 8;
     const int max_rows = separable ? std::min(ctx->height, sep_rows) : std::max(1, std::min(ctx->height, (48 * 1024) / (wpr * 4)));
     const int chunk_max = 16384;
+    struct part { int cn, band_rows, bands; size_t off; };
+    std::vector<part> parts;
+    size_t total = 0;
     for (int p0 = 0; p0 < nposes; p0 += chunk_max) {
         const int cn = nposes - p0 < chunk_max ? nposes - p0 : chunk_max;
         const int want_bands = std::min(cdiv(ctx->height, 8), cdiv(2048, cn));
         const int band_rows = std::max(1, std::min(max_rows, cdiv(ctx->height, std::max(1, want_bands))));
-        const int bands = cdiv(ctx->height, band_rows);
+        parts.push_back({cn, band_rows, cdiv(ctx->height, band_rows), total});
+        total += (size_t)cn * parts.back().bands;
+    }
+    if ((rc = ensure(ctx, ctx->areas, total * 8))) return rc;
+    int p0 = 0;
+    for (const part &pt : parts) {
+        const int band_rows = pt.band_rows;
         const double *pd = slots_dev ? proj_dev : proj_dev + (size_t)p0 * 12;
         const int *sd = slots_dev ? slots_dev + p0 : nullptr;
+        unsigned long long *sums = (unsigned long long *)ctx->areas.p + pt.off;
         if (separable) {
             const int nh = band_rows + 2 * half - 1;
             const size_t lds = (size_t)(nh + (nh + 7) / 8) * wpr * 4;
-            hipLaunchKernelGGL(k_coverage, dim3(cn, bands), dim3(256), lds, ctx->stream, q, cn, pd, sd, eps, all_matches,
-                               band_rows, wpr, (unsigned long long *)ctx->areas.p + p0);
+            hipLaunchKernelGGL(k_coverage, dim3(pt.cn, pt.bands), dim3(256), lds, ctx->stream, q, pt.cn, pd, sd, eps, all_matches,
+                               band_rows, wpr, sums);
         } else {
-            hipLaunchKernelGGL(k_coverage_direct, dim3(cn, bands), dim3(256), (size_t)band_rows * wpr * 4, ctx->stream, q, cn, pd, sd, eps,
-                               all_matches, band_rows, wpr, (unsigned long long *)ctx->areas.p + p0);
+            hipLaunchKernelGGL(k_coverage_direct, dim3(pt.cn, pt.bands), dim3(256), (size_t)band_rows * wpr * 4, ctx->stream, q, pt.cn, pd, sd, eps,
+                               all_matches, band_rows, wpr, sums);
         }
         HIPCHK(ctx, hipGetLastError());
+        p0 += pt.cn;
     }
-    if ((rc = download(ctx, areas_host, ctx->areas.p, (size_t)nposes * 8))) return rc;
-    return pose_amd_synchronize(ctx);
+    ctx->band_host.resize(total);
+    if ((rc = download(ctx, ctx->band_host.data(), ctx->areas.p, total * 8)) || (rc = pose_amd_synchronize(ctx))) return rc;
+    p0 = 0;
+    for (const part &pt : parts) {
+        for (int i = 0; i < pt.cn; ++i) {
+            int64_t a = 0;
+            for (int b = 0; b < pt.bands; ++b) a += (int64_t)ctx->band_host[pt.off + (size_t)i * pt.bands + b];
+            areas_host[p0 + i] = a;
+        }
+        p0 += pt.cn;
+    }
+    return POSE_AMD_OK;
 }
 
 int pose_amd_coverage_batch(pose_amd_ctx *ctx, int nposes, const double *P, double eps, int64_t *areas, int64_t *area_all)
@@ -763,9 +785,8 @@ int pose_amd_ransac_run(pose_amd_ctx *ctx, const pose_amd_params *prm, pose_amd_
     int64_t area_all = 0;
     if (coverage) {
         if (ctx->area_all < 0) {        // depends on the query only
-            double dummy[12] = {0};
-            if ((rc = upload(ctx, ctx->in1, dummy, 96)) || (rc = coverage_dev(ctx, 1, (const double *)ctx->in1.p, prm->eps, 1, &ctx->area_all)))
-                return rc;
+            // the all-matches map reads no pose: any device address will do for the argument
+            if ((rc = coverage_dev(ctx, 1, (const double *)ctx->proj.p, prm->eps, 1, &ctx->area_all))) return rc;
         }
         area_all = ctx->area_all;
     }
