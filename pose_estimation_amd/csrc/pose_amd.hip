@@ -452,9 +452,11 @@ static int launch_score(pose_amd_ctx *ctx, const lane_io &io, int nslots, const 
         if ((rc = ensure_feat(ctx, io.stream))) return rc;
         if ((rc = ensure(ctx, *io.vlist, (size_t)nslots * 4))) return rc;
         if (!io.vcount->p) {
-            // {valid poses, blocks done}: zeroed once, the scoring kernel's last block re-arms it
-            if ((rc = ensure(ctx, *io.vcount, 8))) return rc;
-            HIPCHK(ctx, hipMemsetAsync(io.vcount->p, 0, 8, io.stream));
+            // {valid poses, blocks done, blocks done per group of poses of a launch that is also cut
+            // along the correspondences (fewer than 1024 groups)}: zeroed once, the scoring kernel
+            // leaves every word at zero again
+            if ((rc = ensure(ctx, *io.vcount, 8 + 1024 * 4))) return rc;
+            HIPCHK(ctx, hipMemsetAsync(io.vcount->p, 0, 8 + 1024 * 4, io.stream));
         }
         // a launch with few poses is also cut along the correspondences, so that it still has a
         // thousand blocks or so; their counts are then added up with atomics
@@ -466,8 +468,8 @@ static int launch_score(pose_amd_ctx *ctx, const lane_io &io, int nslots, const 
                            (unsigned int *)io.vcount->p, counts_dev, gy > 1 ? 1 : 0);
         hipLaunchKernelGGL(k_score_mfma, dim3(pose_batches, gy), dim3(MS_THREADS), 0, io.stream, q, ctx->centre, (const uint4 *)ctx->feat.p,
                            ntiles, tpb, proj_dev, (const int *)io.vlist->p, (unsigned int *)io.vcount->p, eps, counts_dev,
-                           fuse_select && gy == 1 ? (unsigned long long *)ctx->sel.p : nullptr);
-        ctx->sel_fused = fuse_select && gy == 1;
+                           fuse_select ? (unsigned long long *)ctx->sel.p : nullptr);
+        ctx->sel_fused = fuse_select;
         HIPCHK(ctx, hipGetLastError());
         return POSE_AMD_OK;
     }

@@ -391,25 +391,42 @@ __global__ __launch_bounds__(MS_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
         }
     }
     __syncthreads();
+    // selection by inlier count folded in: the best (count, lowest slot) key of the block's poses
+    // and their number go where the selection kernel would put them
+    auto publish_best = [&](int cnt) {
+        unsigned long long key = tid < nblk ? ((unsigned long long)(unsigned)cnt << 32) | (0xFFFFFFFFu - (unsigned)s_slot[tid]) : 0ull;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { const unsigned long long k2 = __shfl_xor(key, o); key = k2 > key ? k2 : key; }
+        unsigned long long *s_key = reinterpret_cast<unsigned long long *>(s_feat);   // the chunk buffer is free by now
+        if (lane == 0) s_key[wave] = key;
+        __syncthreads();
+        if (tid == 0) {
+            for (int w = 1; w < MS_WAVES; ++w) key = s_key[w] > key ? s_key[w] : key;
+            atomicMax(&sel[0], key);
+            atomicAdd(&sel[2], (unsigned long long)nblk);
+        }
+    };
     if (gridDim.y == 1) {
         for (int i = tid; i < nblk; i += MS_THREADS) counts[s_slot[i]] = s_cnt[i];
+        if (sel) publish_best(s_cnt[tid]);
+    } else {
+        // The adds are device-scope atomics, performed where all compute dies see them; taking
+        // their return values makes the thread wait until that has happened, so that the counter
+        // below orders the blocks without a release fence (which would write back the L2).
+        for (int i = tid; i < nblk; i += MS_THREADS)
+            if (s_cnt[i]) { const int before = atomicAdd(&counts[s_slot[i]], s_cnt[i]); asm volatile("" :: "v"(before)); }
         if (sel) {
-            // selection by inlier count folded in: the block's best (count, lowest slot) key and
-            // its number of poses go where the selection kernel would put them
-            unsigned long long key = tid < nblk ? ((unsigned long long)(unsigned)s_cnt[tid] << 32) | (0xFFFFFFFFu - (unsigned)s_slot[tid]) : 0ull;
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) { const unsigned long long k2 = __shfl_xor(key, o); key = k2 > key ? k2 : key; }
-            unsigned long long *s_key = reinterpret_cast<unsigned long long *>(s_feat);   // the chunk buffer is free by now
-            if (lane == 0) s_key[wave] = key;
+            // the block that finishes last among those that share these poses (nvalid_p[2 + x]
+            // counts them and is left at zero again) reads the summed counts and publishes
+            unsigned int *batch_done = nvalid_p + 2;
             __syncthreads();
-            if (tid == 0) {
-                for (int w = 1; w < MS_WAVES; ++w) key = s_key[w] > key ? s_key[w] : key;
-                atomicMax(&sel[0], key);
-                atomicAdd(&sel[2], (unsigned long long)nblk);
+            if (tid == 0) s_dense[0] = atomicAdd(&batch_done[blockIdx.x], 1u) == gridDim.y - 1 ? 1 : 0;   // s_dense is free by now
+            __syncthreads();
+            if (s_dense[0]) {
+                if (tid == 0) __hip_atomic_store(&batch_done[blockIdx.x], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                publish_best(tid < nblk ? __hip_atomic_load(&counts[s_slot[tid]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0);
             }
         }
-    } else {
-        for (int i = tid; i < nblk; i += MS_THREADS) if (s_cnt[i]) atomicAdd(&counts[s_slot[i]], s_cnt[i]);
     }
     leave();
 }

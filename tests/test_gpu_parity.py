@@ -586,7 +586,7 @@ def test_two_stream_split_gives_the_same_run(ctx):
 
 
 def test_selection_inside_the_scoring_kernel_equals_the_selection_kernel(ctx):
-    """A large fixed-budget chunk selected by inlier count gets its selection from the matrix-core
+    """A fixed-budget chunk selected by inlier count gets its selection from the matrix-core
     scoring kernel; a context that scores with the packed kernel runs the selection kernel.  Best
     hypothesis (lowest slot among equal counts: few matches give many ties), counts and the number
     of scored poses must agree."""
@@ -597,7 +597,10 @@ def test_selection_inside_the_scoring_kernel_equals_the_selection_kernel(ctx):
     finally:
         del os.environ["POSE_AMD_SCORE"]
     with ref_ctx:
-        for known, n, frac, H in ((False, 2000, 0.2, 1 << 17), (True, 40, 0.5, 1 << 18), (False, 33, 0.0, 1 << 17)):
+        for known, n, frac, H in ((False, 2000, 0.2, 1 << 17), (True, 40, 0.5, 1 << 18), (False, 33, 0.0, 1 << 17),
+                                  # launches that are also cut along the correspondences: the last block of a
+                                  # group of poses publishes; no inliers at all gives many equal counts
+                                  (True, 2000, 0.3, 4096), (False, 5000, 0.2, 2000), (True, 1500, 0.0, 4096), (False, 3000, 0.0, 1500)):
             q = synth.make_query(n, frac, 77 + n, known_focal=known)
             res = []
             for c in (ctx, ref_ctx):
