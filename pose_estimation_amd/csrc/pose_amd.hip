@@ -529,7 +529,7 @@ static int coverage_dev(pose_amd_ctx *ctx, int nposes, const double *proj_dev, d
     int rc;
     // Bands of image rows.  A band of R rows needs R + 2h - 1 painted rows (h: half box width) plus
     // one row of unions per eight of them in LDS, 64 KB at most; thinner bands when few poses are
-    // evaluated, so that about 2 000 blocks exist and a single pose (the all-matches map) is not
+    // evaluated, so that a few hundred blocks exist and a single pose (the all-matches map) is not
     // left to a handful of them.  Images too wide for that (the 2h extra rows alone exceed the
     // LDS) take the kernel that paints whole boxes into a band bitmap of at most 48 KB.
     // Every block writes the sum of its band; the bands of a pose are added up here, so the
@@ -546,7 +546,7 @@ static int coverage_dev(pose_amd_ctx *ctx, int nposes, const double *proj_dev, d
     size_t total = 0;
     for (int p0 = 0; p0 < nposes; p0 += chunk_max) {
         const int cn = nposes - p0 < chunk_max ? nposes - p0 : chunk_max;
-        const int want_bands = std::min(cdiv(ctx->height, 8), cdiv(2048, cn));
+        const int want_bands = std::min(cdiv(ctx->height, 8), cdiv(512, cn));
         const int band_rows = std::max(1, std::min(max_rows, cdiv(ctx->height, std::max(1, want_bands))));
         parts.push_back({cn, band_rows, cdiv(ctx->height, band_rows), total});
         total += (size_t)cn * parts.back().bands;
