@@ -449,7 +449,12 @@ static int launch_score(pose_amd_ctx *ctx, const lane_io &io, int nslots, const 
     if (use_mfma_screen(ctx, nslots, mask_dev != nullptr)) {
         int rc;
         const int ntiles = cdiv(ctx->n, 32);
-        if ((rc = ensure_feat(ctx, io.stream))) return rc;
+        // the feature image of a query is built by extra blocks of the first compaction launch
+        const bool build_feat = !ctx->feat_ready;
+        if (build_feat) {
+            if ((rc = ensure(ctx, ctx->feat, (size_t)ntiles * MS_TILE_BYTES))) return rc;
+            ctx->feat_ready = true;
+        }
         if ((rc = ensure(ctx, *io.vlist, (size_t)nslots * 4))) return rc;
         if (!io.vcount->p) {
             // {valid poses, blocks done, blocks done per group of poses of a launch that is also cut
@@ -464,8 +469,9 @@ static int launch_score(pose_amd_ctx *ctx, const lane_io &io, int nslots, const 
         int gy = pose_batches >= 1024 ? 1 : std::min(nchunks, std::max(1, 1024 / pose_batches));
         const int tpb = cdiv(nchunks, gy) * MS_CHUNK_TILES;
         gy = cdiv(ntiles, tpb);
-        hipLaunchKernelGGL(k_compact_valid, dim3(cdiv(nslots, MS_COMPACT_SLOTS)), dim3(256), 0, io.stream, nslots, nsol_dev, maxsol, (int *)io.vlist->p,
-                           (unsigned int *)io.vcount->p, counts_dev, gy > 1 ? 1 : 0);
+        hipLaunchKernelGGL(k_compact_valid, dim3(cdiv(nslots, MS_COMPACT_SLOTS) + (build_feat ? cdiv(ntiles * 32, 256) : 0)), dim3(256), 0, io.stream,
+                           nslots, nsol_dev, maxsol, (int *)io.vlist->p, (unsigned int *)io.vcount->p, counts_dev, gy > 1 ? 1 : 0, q, ctx->centre,
+                           ntiles, build_feat ? (uint4 *)ctx->feat.p : nullptr);
         hipLaunchKernelGGL(k_score_mfma, dim3(pose_batches, gy), dim3(MS_THREADS), 0, io.stream, q, ctx->centre, (const uint4 *)ctx->feat.p,
                            ntiles, tpb, proj_dev, (const int *)io.vlist->p, (unsigned int *)io.vcount->p, eps, counts_dev,
                            fuse_select ? (unsigned long long *)ctx->sel.p : nullptr);

@@ -77,9 +77,8 @@ __device__ __forceinline__ void bf16_split(float a, unsigned &hi, unsigned &lo)
 struct query_centre { float cx, cy, cz, xmaxc; };   // centre of the 3-D points and max |X - c| over the query
 
 // Feature image of the query, 1536 bytes per tile of 32 correspondences (layout above).
-__global__ void k_make_feat(query_dev q, query_centre qc, int ntiles, uint4 *__restrict__ feat)
+__device__ __forceinline__ void make_feat_entry(const query_dev &q, const query_centre &qc, int ntiles, uint4 *__restrict__ feat, int i)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= ntiles * 32) return;
     float f[8];
     if (i < q.n) {
@@ -101,14 +100,27 @@ __global__ void k_make_feat(query_dev q, query_centre qc, int ntiles, uint4 *__r
     t[64 + r] = make_uint4(p0, p1, p0, p1);
 }
 
+__global__ void k_make_feat(query_dev q, query_centre qc, int ntiles, uint4 *__restrict__ feat)
+{
+    make_feat_entry(q, qc, ntiles, feat, blockIdx.x * blockDim.x + threadIdx.x);
+}
+
 // Dense list of the valid pose slots (slot % maxsol < nsol[slot / maxsol]); order unspecified.
 // A block of 256 threads handles MS_COMPACT_SLOTS consecutive slots with one atomic reservation.
 // counts[] of the slots that are not valid is set to 0 (the scoring kernel writes the others), of
 // all slots when zero_all is set (the scoring kernel then adds to them from several blocks).
+// Blocks beyond the ones the slots need (feat != null) build the query's feature image, so that
+// the first scoring launch of a query needs no launch of its own for it.
 constexpr int MS_COMPACT_SLOTS = 4096;
 __global__ __launch_bounds__(256) void k_compact_valid(int nslots, const int *__restrict__ nsol, int maxsol, int *__restrict__ vlist,
-                                                       unsigned int *__restrict__ counter, int *__restrict__ counts, int zero_all)
+                                                       unsigned int *__restrict__ counter, int *__restrict__ counts, int zero_all,
+                                                       query_dev q, query_centre qc, int ntiles, uint4 *__restrict__ feat)
 {
+    const int slot_blocks = (nslots + MS_COMPACT_SLOTS - 1) / MS_COMPACT_SLOTS;
+    if ((int)blockIdx.x >= slot_blocks) {
+        make_feat_entry(q, qc, ntiles, feat, ((int)blockIdx.x - slot_blocks) * 256 + (int)threadIdx.x);
+        return;
+    }
     __shared__ int s_n[4];
     __shared__ unsigned s_base;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
