@@ -82,6 +82,12 @@ int pose_amd_score_batch(pose_amd_ctx *ctx, int nposes, const double *P, double 
 int pose_amd_coverage_batch(pose_amd_ctx *ctx, int nposes, const double *P, double eps, int64_t *areas,
                             int64_t *area_all);
 
+/* QueryProcessor::Project (query_processor.hpp:44-49, query_processor.cpp:46-86) for `nposes`
+ * (<= 65535) projection matrices against the current query:
+ * pts2d[(p*n + i)*2 + {0,1}] = (p0/p2, p1/p2) of p = P_p [X_i Y_i Z_i 1]^T (fitpoints_2d);
+ * pts3d (may be NULL): n*3 doubles, the world points (fitpoints_3d; the same for every pose). */
+int pose_amd_project_batch(pose_amd_ctx *ctx, int nposes, const double *P, double *pts2d, double *pts3d);
+
 /* ---- sampling (replaces GetRandomSelector / GetRandomProbability, pose_utils.cpp:58-84) -- */
 /* Generates the ordered sample tuples of hypotheses [hyp_begin, hyp_begin+hyp_count) on the
  * device with the counter-based generator (Philox4x32-10 keyed by seed, counter =
@@ -123,6 +129,12 @@ int pose_amd_ransac_run(pose_amd_ctx *ctx, const pose_amd_params *params, pose_a
 /* Inlier mask (n bytes, 0/1) of the pose kept by the last pose_amd_ransac_run
  * (fitted_matches, basic.cpp:224). */
 int pose_amd_best_mask(pose_amd_ctx *ctx, uint8_t *mask);
+
+/* The final projection of Process (query_processor_basic.cpp:296-307,
+ * query_processor_advanced.cpp:609-621): Project on the kept pose for its fitted matches.
+ * mask (may be NULL) as pose_amd_best_mask; fit2d / fit3d: room for n*2 / n*3 doubles, filled
+ * with the *nfit fitted matches in match order (fitpoints_2d / fitpoints_3d of Query). */
+int pose_amd_best_fit(pose_amd_ctx *ctx, uint8_t *mask, double *fit2d, double *fit3d, int *nfit);
 
 /* ---- many queries (the loop over queries of benchmark.cpp:24-36) -------------------------- */
 typedef struct {

@@ -4,7 +4,7 @@
 // reference's call sites compile unchanged once its solver/processor headers are replaced:
 //   P3p::computePoses / solveQuartic                     (P3p.hpp:59-60)
 //   P4pf::P4Pf_m / P4Pf                                  (P4pf.hpp:39-41)
-//   QueryProcessor::TestHypothesis, QueryProcessorBasic/Advanced::Process
+//   QueryProcessor::Project, TestHypothesis, QueryProcessorBasic/Advanced::Process
 //                                                        (query_processor.hpp:33-73)
 // The reference passes Eigen matrices by value; Eigen is not a dependency here, so the small
 // fixed-size type Mat<R,C> below is used instead.  It is column-major and contiguous like
@@ -38,6 +38,7 @@ struct Mat {
 };
 using Matrix3d = Mat<3, 3>;
 using Vector3d = Mat<3, 1>;
+using Vector2d = Mat<2, 1>;
 
 // One context per device, created on first use (the reference creates one solver object per
 // Process call, basic.cpp:100-101; contexts are heavier, so they are shared per thread).
@@ -155,7 +156,14 @@ public:
     void set_focal_length(double f) { focal_ = f; }
     int image_width() const { return w_; }
     int image_height() const { return h_; }
+    void set_image_width(int w) { w_ = w; }
+    void set_image_height(int h) { h_ = h; }
     std::vector<SIFT_keypoint> &sift_keypoints() { return keys_; }
+    // projections / world points of the fitted matches, filled by Process (query_loader.hpp:76-79)
+    std::vector<Vector2d> &fitpoints_2d() { return fit2d_; }
+    std::vector<Vector3d> &fitpoints_3d() { return fit3d_; }
+    void set_fitpoints_2d(const std::vector<Vector2d> &p) { fit2d_ = p; }
+    void set_fitpoints_3d(const std::vector<Vector3d> &p) { fit3d_ = p; }
     // query_loader.cpp:222-254
     bool ComputeMatrices(Device *dev = nullptr)
     {
@@ -175,6 +183,8 @@ private:
     Matrix3d rot_;
     Mat<3, 4> proj_;
     std::vector<SIFT_keypoint> keys_;
+    std::vector<Vector2d> fit2d_;
+    std::vector<Vector3d> fit3d_;
     int w_, h_;
 };
 
@@ -187,6 +197,26 @@ public:
     explicit QueryProcessor(Device *dev = nullptr) : dev_(dev ? dev : &Device::current()) {}
     virtual ~QueryProcessor() {}
     virtual bool Process(Query &query, std::vector<SiftMatch> &good_matches, std::vector<feature_3D_info> &sifts) = 0;
+
+    // Reprojection of `matches` with query.proj_matrix() (query_processor.cpp:46-86).
+    bool Project(Query &query, std::vector<Vector2d> &fitpoints_2d, std::vector<Vector3d> &fitpoints_3d, std::vector<SiftMatch> &matches,
+                 std::vector<SIFT_keypoint> &sift_keypoints, std::vector<feature_3D_info> &sifts)
+    {
+        const size_t n = matches.size();
+        fitpoints_2d.resize(n);
+        fitpoints_3d.resize(n);
+        if (n == 0) return true;
+        solver_focal_ = query.focal_length();
+        upload(query, matches, sift_keypoints, sifts, false);
+        const Mat<3, 4> Pm = query.proj_matrix();
+        double P[12];
+        for (int r = 0; r < 3; ++r)
+            for (int c = 0; c < 4; ++c) P[4 * r + c] = Pm(r, c);
+        std::vector<double> p2(2 * n), p3(3 * n);
+        dev_->check(pose_amd_project_batch(dev_->ctx(), 1, P, p2.data(), p3.data()), "project_batch");
+        for (size_t i = 0; i < n; ++i) { fitpoints_2d[i] = Vector2d(p2.data() + 2 * i); fitpoints_3d[i] = Vector3d(p3.data() + 3 * i); }
+        return true;
+    }
 
     // Inliers of query.proj_matrix() among `matches` and the coverage quality (query_processor.cpp:88-177).
     std::vector<SiftMatch> TestHypothesis(Query &query, std::vector<SiftMatch> &matches, std::vector<SIFT_keypoint> &sift_keypoints,
@@ -256,11 +286,17 @@ protected:
         r.steps += result.steps;
         if (!better) { result.steps = r.steps; return false; }
         result = r;
-        std::vector<uint8_t> mask(matches.size());
-        dev_->check(pose_amd_best_mask(dev_->ctx(), mask.data()), "best_mask");
+        // fitted matches and their final projection (basic.cpp:296-307) in one call
+        const size_t n = matches.size();
+        std::vector<uint8_t> mask(n);
+        std::vector<double> p2(2 * n), p3(3 * n);
+        int nfit = 0;
+        dev_->check(pose_amd_best_fit(dev_->ctx(), mask.data(), p2.data(), p3.data(), &nfit), "best_fit");
         fitted_matches.clear();
-        for (size_t i = 0; i < matches.size(); ++i)
+        for (size_t i = 0; i < n; ++i)
             if (mask[i]) fitted_matches.push_back(matches[i]);
+        fit2d_.resize((size_t)nfit); fit3d_.resize((size_t)nfit);
+        for (int i = 0; i < nfit; ++i) { fit2d_[(size_t)i] = Vector2d(p2.data() + 2 * i); fit3d_[(size_t)i] = Vector3d(p3.data() + 3 * i); }
         if (solver_focal_ == 0.0) query.set_focal_length(r.focal);      // unknown focal: the P4Pf estimate
         query.set_camera_position(Vector3d(r.C));
         Matrix3d Rc;
@@ -280,6 +316,15 @@ public:
     uint32_t query_id = 0;
 
 protected:
+    // what the reference does after its loop (basic.cpp:296-307): final matrices, reprojected fitted matches
+    void finish(Query &query)
+    {
+        query.ComputeMatrices(dev_);
+        query.set_fitpoints_2d(fit2d_);
+        query.set_fitpoints_3d(fit3d_);
+    }
+    std::vector<Vector2d> fit2d_;
+    std::vector<Vector3d> fit3d_;
     Device *dev_;
     double solver_focal_ = 0.0;             // focal length the query came with: 0 selects P4Pf (basic.cpp:154)
 };
@@ -291,12 +336,12 @@ public:
     // query_processor_basic.cpp:105-293
     bool Process(Query &query, std::vector<SiftMatch> &good_matches, std::vector<feature_3D_info> &sifts) override
     {
-        samples.clear(); fitted_matches.clear(); std::memset(&result, 0, sizeof result);
+        samples.clear(); fitted_matches.clear(); fit2d_.clear(); fit3d_.clear(); std::memset(&result, 0, sizeof result);
         solver_focal_ = query.focal_length();
         upload(query, good_matches, query.sift_keypoints(), sifts, false);
         run(query, good_matches, POSE_AMD_SAMPLE_BASIC, 0, max_ransac_steps, 1);
         samples.resize((size_t)result.steps * 4);
-        query.ComputeMatrices(dev_);
+        finish(query);
         return true;
     }
 
@@ -366,19 +411,25 @@ public:
     // outside this library): may append matches; return false to skip.
     bool (*backmatching)(std::vector<SiftMatch> &good_matches, void *user) = nullptr;
     void *backmatching_user = nullptr;
+    int best_leg = 0;            // which leg kept the pose (0: before, 1: after backmatching); result.best_hyp counts within it
+    bool backmatched = false;    // the second leg ran
     // query_processor_advanced.cpp:296-606
     bool Process(Query &query, std::vector<SiftMatch> &good_matches, std::vector<feature_3D_info> &sifts) override
     {
-        samples.clear(); fitted_matches.clear(); std::memset(&result, 0, sizeof result);
+        samples.clear(); fitted_matches.clear(); fit2d_.clear(); fit3d_.clear(); std::memset(&result, 0, sizeof result);
         solver_focal_ = query.focal_length();
+        best_leg = 0; backmatched = false;
         upload(query, good_matches, query.sift_keypoints(), sifts, true);
         run(query, good_matches, POSE_AMD_SAMPLE_ADVANCED, 0, max_ransac_steps, 0);
+        // the size of good_matches before backmatching decides (advanced.cpp:587-589)
         const uint32_t thresh = std::min<uint32_t>((uint32_t)good_matches.size() / inlier_divisor, inlier_absolute);
         if (backmatching && (result.found ? result.inliers : 0u) < thresh && backmatching(good_matches, backmatching_user)) {
+            backmatched = true;
             upload(query, good_matches, query.sift_keypoints(), sifts, true);
-            run(query, good_matches, POSE_AMD_SAMPLE_ADVANCED, max_ransac_steps, max_ransac_steps, 0);
+            // steps restart, the kept pose and its quality carry over (advanced.cpp:597-602)
+            if (run(query, good_matches, POSE_AMD_SAMPLE_ADVANCED, max_ransac_steps, max_ransac_steps, 0)) best_leg = 1;
         }
-        query.ComputeMatrices(dev_);
+        finish(query);
         return true;
     }
 };

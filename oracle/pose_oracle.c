@@ -10,158 +10,79 @@
 #include <string.h>
 
 /* ===================================================================================== */
-/* complex helpers that spell out what libstdc++'s std::complex<double> does, so that     */
-/* signed zeros and branch cuts follow the reference binary (g++ on x86-64 Linux).        */
+/* P3P in double and long double                                                          */
 /* ===================================================================================== */
-typedef struct { double re, im; } cd;
-static cd cd_make(double re, double im) { cd z = {re, im}; return z; }
-static cd cd_add(cd a, cd b) { return cd_make(a.re + b.re, a.im + b.im); }
-static cd cd_sub(cd a, cd b) { return cd_make(a.re - b.re, a.im - b.im); }
-static cd cd_neg(cd a) { return cd_make(-a.re, -a.im); }
-static cd cd_scale(cd a, double s) { return cd_make(a.re * s, a.im * s); }      /* complex*T, T*complex */
-static cd cd_divs(cd a, double s) { return cd_make(a.re / s, a.im / s); }       /* complex/T */
-static cd cd_adds(cd a, double s) { return cd_make(a.re + s, a.im); }           /* T+complex, complex+T */
-static cd cd_rsub(double s, cd a) { return cd_make(-a.re + s, -a.im); }         /* T-complex: r=-y; r+=x */
-static cd cd_div(cd a, cd b)                                                     /* complex/complex (__divdc3) */
-{
-    double complex q = CMPLX(a.re, a.im) / CMPLX(b.re, b.im);
-    return cd_make(creal(q), cimag(q));
-}
-static cd cd_sqrt(cd a) { double complex q = csqrt(CMPLX(a.re, a.im)); return cd_make(creal(q), cimag(q)); }
-/* std::pow(const complex<double>&, const double&) as libstdc++ writes it. */
-static cd cd_pow(cd x, double y)
-{
-    if (x.im == 0.0 && x.re > 0.0) return cd_make(pow(x.re, y), 0.0);
-    double complex t = clog(CMPLX(x.re, x.im));
-    double rho = exp(y * creal(t)), theta = y * cimag(t);
-    return cd_make(rho * cos(theta), rho * sin(theta));                          /* std::polar */
-}
+#define REAL double
+#define CPLX double complex
+#define FN(name) name##_d
+#define R_SQRT sqrt
+#define R_POW pow
+#define R_EXP exp
+#define R_COS cos
+#define R_SIN sin
+#define C_SQRT csqrt
+#define C_LOG clog
+#define C_REAL creal
+#define C_IMAG cimag
+#define C_MAKE CMPLX
+#include "p3p_core.inc"
+#undef REAL
+#undef CPLX
+#undef FN
+#undef R_SQRT
+#undef R_POW
+#undef R_EXP
+#undef R_COS
+#undef R_SIN
+#undef C_SQRT
+#undef C_LOG
+#undef C_REAL
+#undef C_IMAG
+#undef C_MAKE
+
+#define REAL long double
+#define CPLX long double complex
+#define FN(name) name##_ld
+#define R_SQRT sqrtl
+#define R_POW powl
+#define R_EXP expl
+#define R_COS cosl
+#define R_SIN sinl
+#define C_SQRT csqrtl
+#define C_LOG clogl
+#define C_REAL creall
+#define C_IMAG cimagl
+#define C_MAKE CMPLXL
+#include "p3p_core.inc"
+#undef REAL
+#undef CPLX
+#undef FN
+#undef R_SQRT
+#undef R_POW
+#undef R_EXP
+#undef R_COS
+#undef R_SIN
+#undef C_SQRT
+#undef C_LOG
+#undef C_REAL
+#undef C_IMAG
+#undef C_MAKE
 
 /* P3p.cpp:238-293 */
-int orc_p3p_solve_quartic(const double factors[5], double roots[4])
-{
-    double A = factors[0], B = factors[1], C = factors[2], D = factors[3], E = factors[4];
-    double A_pw2 = A * A, B_pw2 = B * B, A_pw3 = A_pw2 * A, B_pw3 = B_pw2 * B, A_pw4 = A_pw3 * A, B_pw4 = B_pw3 * B;
-    double alpha = -3 * B_pw2 / (8 * A_pw2) + C / A;
-    double beta = B_pw3 / (8 * A_pw3) - B * C / (2 * A_pw2) + D / A;
-    double gamma = -3 * B_pw4 / (256 * A_pw4) + B_pw2 * C / (16 * A_pw3) - B * D / (4 * A_pw2) + E / A;
-    double alpha_pw2 = alpha * alpha, alpha_pw3 = alpha_pw2 * alpha;
-    cd P = cd_make(-alpha_pw2 / 12 - gamma, 0);
-    cd Q = cd_make(-alpha_pw3 / 108 + alpha * gamma / 3 - pow(beta, 2) / 8, 0);
-    cd R = cd_add(cd_divs(cd_neg(Q), 2.0), cd_sqrt(cd_add(cd_divs(cd_pow(Q, 2.0), 4.0), cd_divs(cd_pow(P, 3.0), 27.0))));
-    cd U = cd_pow(R, 1.0 / 3.0);
-    cd y;
-    if (U.re == 0)
-        y = cd_rsub(-5.0 * alpha / 6.0, cd_pow(Q, 1.0 / 3.0));
-    else
-        y = cd_add(cd_rsub(-5.0 * alpha / 6.0, cd_div(P, cd_scale(U, 3.0))), U);
-    cd w = cd_sqrt(cd_adds(cd_scale(y, 2.0), alpha));
-    cd two_beta_w = cd_div(cd_make(2.0 * beta, 0), w);
-    cd base = cd_adds(cd_scale(y, 2.0), 3.0 * alpha);
-    cd s_plus = cd_sqrt(cd_neg(cd_add(base, two_beta_w)));
-    cd s_minus = cd_sqrt(cd_neg(cd_sub(base, two_beta_w)));
-    double shift = -B / (4.0 * A);
-    roots[0] = cd_adds(cd_scale(cd_add(w, s_plus), 0.5), shift).re;
-    roots[1] = cd_adds(cd_scale(cd_sub(w, s_plus), 0.5), shift).re;
-    roots[2] = cd_adds(cd_scale(cd_add(cd_neg(w), s_minus), 0.5), shift).re;
-    roots[3] = cd_adds(cd_scale(cd_sub(cd_neg(w), s_minus), 0.5), shift).re;
-    return 0;
-}
-
-static void v_cross(const double a[3], const double b[3], double c[3])
-{
-    c[0] = a[1] * b[2] - a[2] * b[1]; c[1] = a[2] * b[0] - a[0] * b[2]; c[2] = a[0] * b[1] - a[1] * b[0];
-}
-static double v_dot(const double a[3], const double b[3]) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
-static double v_norm(const double a[3]) { return sqrt(v_dot(a, a)); }
-static void m_vec(const double M[9], const double v[3], double o[3])
-{
-    for (int r = 0; r < 3; ++r) o[r] = M[3 * r] * v[0] + M[3 * r + 1] * v[1] + M[3 * r + 2] * v[2];
-}
-
+int orc_p3p_solve_quartic(const double factors[5], double roots[4]) { return p3p_solve_quartic_d(factors, roots); }
 /* P3p.cpp:64-236 */
-int orc_p3p_compute_poses(const double fcols[9], const double pcols[9], double sol[48])
+int orc_p3p_compute_poses(const double fcols[9], const double pcols[9], double sol[48]) { return p3p_compute_poses_d(fcols, pcols, sol); }
+/* The same computation in long double, results rounded to double: the conditioning gate. */
+int orc_p3p_compute_poses_ld(const double fcols[9], const double pcols[9], double sol[48])
 {
-    double P1[3], P2[3], P3[3], f1[3], f2[3], f3[3], t1[3], t2[3], cr[3];
-    memcpy(P1, pcols, 24); memcpy(P2, pcols + 3, 24); memcpy(P3, pcols + 6, 24);
-    for (int k = 0; k < 3; ++k) { t1[k] = P2[k] - P1[k]; t2[k] = P3[k] - P1[k]; }
-    v_cross(t1, t2, cr);
-    if (v_norm(cr) == 0) return -1;
-    memcpy(f1, fcols, 24); memcpy(f2, fcols + 3, 24); memcpy(f3, fcols + 6, 24);
-    double T[9], e1[3], e2[3], e3[3], tmp[3];
-    for (int pass = 0; pass < 2; ++pass) {
-        memcpy(e1, f1, 24);
-        v_cross(f1, f2, e3);
-        double n = v_norm(e3);
-        for (int k = 0; k < 3; ++k) e3[k] = e3[k] / n;
-        v_cross(e3, e1, e2);
-        memcpy(T, e1, 24); memcpy(T + 3, e2, 24); memcpy(T + 6, e3, 24);
-        m_vec(T, f3, tmp);
-        memcpy(f3, tmp, 24);
-        if (pass == 0 && f3[2] > 0) {                                            /* :103-122 */
-            memcpy(f1, fcols + 3, 24); memcpy(f2, fcols, 24); memcpy(f3, fcols + 6, 24);
-            memcpy(P1, pcols + 3, 24); memcpy(P2, pcols, 24); memcpy(P3, pcols + 6, 24);
-            continue;
-        }
-        break;
-    }
-    double n1[3], n2[3], n3[3], N[9], d[3];
-    for (int k = 0; k < 3; ++k) n1[k] = P2[k] - P1[k];
-    { double n = v_norm(n1); for (int k = 0; k < 3; ++k) n1[k] = n1[k] / n; }
-    for (int k = 0; k < 3; ++k) d[k] = P3[k] - P1[k];
-    v_cross(n1, d, n3);
-    { double n = v_norm(n3); for (int k = 0; k < 3; ++k) n3[k] = n3[k] / n; }
-    v_cross(n3, n1, n2);
-    memcpy(N, n1, 24); memcpy(N + 3, n2, 24); memcpy(N + 6, n3, 24);
-    m_vec(N, d, tmp);
-    memcpy(P3, tmp, 24);
-    for (int k = 0; k < 3; ++k) d[k] = P2[k] - P1[k];
-    double d_12 = v_norm(d);
-    double f_1 = f3[0] / f3[2], f_2 = f3[1] / f3[2], p_1 = P3[0], p_2 = P3[1];
-    double cos_beta = v_dot(f1, f2);
-    double b = 1 / (1 - pow(cos_beta, 2)) - 1;
-    b = cos_beta < 0 ? -sqrt(b) : sqrt(b);
-    double f_1_pw2 = pow(f_1, 2), f_2_pw2 = pow(f_2, 2), p_1_pw2 = pow(p_1, 2), p_1_pw3 = p_1_pw2 * p_1,
-           p_1_pw4 = p_1_pw3 * p_1, p_2_pw2 = pow(p_2, 2), p_2_pw3 = p_2_pw2 * p_2, p_2_pw4 = p_2_pw3 * p_2,
-           d_12_pw2 = pow(d_12, 2), b_pw2 = pow(b, 2);
-    double factors[5];
-    factors[0] = -f_2_pw2 * p_2_pw4 - p_2_pw4 * f_1_pw2 - p_2_pw4;
-    factors[1] = 2 * p_2_pw3 * d_12 * b + 2 * f_2_pw2 * p_2_pw3 * d_12 * b - 2 * f_2 * p_2_pw3 * f_1 * d_12;
-    factors[2] = -f_2_pw2 * p_2_pw2 * p_1_pw2 - f_2_pw2 * p_2_pw2 * d_12_pw2 * b_pw2 - f_2_pw2 * p_2_pw2 * d_12_pw2
-               + f_2_pw2 * p_2_pw4 + p_2_pw4 * f_1_pw2 + 2 * p_1 * p_2_pw2 * d_12
-               + 2 * f_1 * f_2 * p_1 * p_2_pw2 * d_12 * b - p_2_pw2 * p_1_pw2 * f_1_pw2
-               + 2 * p_1 * p_2_pw2 * f_2_pw2 * d_12 - p_2_pw2 * d_12_pw2 * b_pw2 - 2 * p_1_pw2 * p_2_pw2;
-    factors[3] = 2 * p_1_pw2 * p_2 * d_12 * b + 2 * f_2 * p_2_pw3 * f_1 * d_12 - 2 * f_2_pw2 * p_2_pw3 * d_12 * b
-               - 2 * p_1 * p_2 * d_12_pw2 * b;
-    factors[4] = -2 * f_2 * p_2_pw2 * f_1 * p_1 * d_12 * b + f_2_pw2 * p_2_pw2 * d_12_pw2 + 2 * p_1_pw3 * d_12
-               - p_1_pw2 * d_12_pw2 + f_2_pw2 * p_2_pw2 * p_1_pw2 - p_1_pw4 - 2 * f_2_pw2 * p_2_pw2 * p_1 * d_12
-               + p_2_pw2 * f_1_pw2 * p_1_pw2 + f_2_pw2 * p_2_pw2 * d_12_pw2 * b_pw2;
-    double roots[4];
-    orc_p3p_solve_quartic(factors, roots);
-    for (int i = 0; i < 4; ++i) {
-        double cot_alpha = (-f_1 * p_1 / f_2 - roots[i] * p_2 + d_12 * b) / (-f_1 * roots[i] * p_2 / f_2 + p_1 - d_12);
-        double cos_theta = roots[i];
-        double sin_theta = sqrt(1 - pow(roots[i], 2));
-        double sin_alpha = sqrt(1 / (pow(cot_alpha, 2) + 1));
-        double cos_alpha = sqrt(1 - pow(sin_alpha, 2));
-        if (cot_alpha < 0) cos_alpha = -cos_alpha;
-        double Cl[3] = {d_12 * cos_alpha * (sin_alpha * b + cos_alpha),
-                        cos_theta * d_12 * sin_alpha * (sin_alpha * b + cos_alpha),
-                        sin_theta * d_12 * sin_alpha * (sin_alpha * b + cos_alpha)};
-        double *o = sol + 12 * i;
-        for (int r = 0; r < 3; ++r) o[r] = P1[r] + (N[r] * Cl[0] + N[3 + r] * Cl[1] + N[6 + r] * Cl[2]);  /* P1 + N^T C */
-        double Rl[9] = {-cos_alpha, -sin_alpha * cos_theta, -sin_alpha * sin_theta,
-                        sin_alpha, -cos_alpha * cos_theta, -cos_alpha * sin_theta,
-                        0, -sin_theta, cos_theta};
-        /* R = N^T * Rl^T * T : evaluate (N^T Rl^T) first, as Eigen's left-to-right product does */
-        double NR[9];
-        for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c)
-            NR[3 * r + c] = N[r] * Rl[3 * c] + N[3 + r] * Rl[3 * c + 1] + N[6 + r] * Rl[3 * c + 2];
-        for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c)
-            o[3 + 3 * r + c] = NR[3 * r] * T[c] + NR[3 * r + 1] * T[3 + c] + NR[3 * r + 2] * T[6 + c];
-    }
-    return 0;
+    long double f[9], p[9], s[48];
+    for (int i = 0; i < 9; ++i) { f[i] = fcols[i]; p[i] = pcols[i]; }
+    int st = p3p_compute_poses_ld(f, p, s);
+    if (st == 0) for (int i = 0; i < 48; ++i) sol[i] = (double)s[i];
+    return st;
 }
+static double v_norm(const double a[3]) { return sqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]); }
+
 
 /* ===================================================================================== */
 /* P4Pf in double and long double                                                         */
@@ -393,16 +314,24 @@ int orc_sample_advanced(uint64_t seed, uint32_t query, uint32_t hyp, int m, uint
 /* RANSAC loop (query_processor_basic.cpp:105-293; advanced variant differs only in       */
 /* max_steps / early_exit, query_processor_advanced.cpp:296-327,445-581)                  */
 /* ===================================================================================== */
-int orc_ransac(const orc_query *q, const orc_ransac_params *p, const uint32_t *samples, unsigned nsamples,
-               orc_ransac_result *res, uint8_t *best_mask)
+/* The state the reference's loop carries from one step to the next, and across the
+ * backmatching reset (query_processor_advanced.cpp:597-602 resets `steps` only). */
+typedef struct {
+    unsigned hyposet;
+    double hypoquality;
+    int64_t best_key;                     /* count or A_f of the kept pose */
+} loop_state;
+
+/* One run of the while loop over the given tuples.  Returns the steps executed; a kept pose
+ * is written to res (with res->best_step relative to this run) and *kept is set. */
+static unsigned ransac_loop(const orc_query *q, const orc_ransac_params *p, const uint32_t *samples, unsigned nsamples,
+                            loop_state *st, orc_ransac_result *res, uint8_t *best_mask, int *kept)
 {
-    memset(res, 0, sizeof *res);
     int p4pfmode = q->focal == 0.0;
-    unsigned hyposet = 0, steps = 0;
-    double hypoquality = 0;
-    int64_t best_key = 0;                 /* count or A_f of the kept pose */
+    unsigned hyposet = st->hyposet, steps = 0;
+    double hypoquality = st->hypoquality;
+    int64_t best_key = st->best_key;
     int64_t area_all = p->select_coverage ? orc_coverage_area(q->n, q->kx, q->ky, NULL, q->width, q->height) : 0;
-    res->area_all = area_all;
     uint8_t *mask = (uint8_t *)malloc((size_t)q->n);
     const double hw = (double)q->width / 2.0, hh = (double)q->height / 2.0;
     while (steps < p->max_steps && steps < nsamples &&
@@ -462,14 +391,72 @@ int orc_ransac(const orc_query *q, const orc_ransac_params *p, const uint32_t *s
                 memcpy(res->C, Cs + 3 * k, 24); memcpy(res->Rc, Rcs + 9 * k, 72);
                 res->hyposet = hyposet; res->area_fit = p->select_coverage ? key : 0;
                 res->best_step = steps; res->best_sol = (unsigned)k;
+                res->area_all = area_all;
                 if (best_mask) memcpy(best_mask, mask, (size_t)q->n);
+                if (kept) *kept = 1;
             }
         }
         ++steps;
     }
-    res->steps = steps;
+    st->hyposet = hyposet; st->hypoquality = hypoquality; st->best_key = best_key;
     free(mask);
+    return steps;
+}
+
+int orc_ransac(const orc_query *q, const orc_ransac_params *p, const uint32_t *samples, unsigned nsamples,
+               orc_ransac_result *res, uint8_t *best_mask)
+{
+    memset(res, 0, sizeof *res);
+    loop_state st = {0, 0.0, 0};
+    res->area_all = p->select_coverage ? orc_coverage_area(q->n, q->kx, q->ky, NULL, q->width, q->height) : 0;
+    res->steps = ransac_loop(q, p, samples, nsamples, &st, res, best_mask, NULL);
     return 0;
+}
+
+/* query_processor_advanced.cpp:296-327 and :583-606: max_steps steps on the matches q1; then,
+ * once, if the kept pose has fewer than min(n1 / inlier_divisor, inlier_absolute) inliers
+ * (n1 = the size of good_matches BEFORE backmatching), the matches become q2 (q1 plus what
+ * Backmatching appended -- the FLANN search itself is outside this path, the caller supplies
+ * its result), the step counter restarts and max_steps more steps run, while hyposet and
+ * hypoquality are carried over (:600-602 are commented out in the reference): a pose of the
+ * second leg wins only if its quality against the NEW all-matches area beats the old ratio.
+ * res->best_step counts from the first step of the leg that kept the pose; *best_leg says
+ * which (0 or 1); res->steps is the total (max_steps or 2 max_steps); best_mask must hold
+ * max(n1, n2) bytes and gets n_of_that_leg entries.  Returns 1 if the second leg ran. */
+int orc_ransac_backmatch(const orc_query *q1, const orc_query *q2, const orc_ransac_params *p, const uint32_t *samples1,
+                         unsigned nsamples1, const uint32_t *samples2, unsigned nsamples2, orc_ransac_result *res,
+                         uint8_t *best_mask, int *best_leg)
+{
+    memset(res, 0, sizeof *res);
+    if (best_leg) *best_leg = 0;
+    loop_state st = {0, 0.0, 0};
+    res->area_all = p->select_coverage ? orc_coverage_area(q1->n, q1->kx, q1->ky, NULL, q1->width, q1->height) : 0;
+    unsigned steps = ransac_loop(q1, p, samples1, nsamples1, &st, res, best_mask, NULL);
+    res->steps = steps;
+    int second = q2 && st.hyposet < (unsigned)q1->n / p->inlier_divisor && st.hyposet < p->inlier_absolute && steps == p->max_steps;
+    if (!second) return 0;
+    orc_ransac_result r2;
+    memset(&r2, 0, sizeof r2);
+    int kept = 0;
+    uint64_t scored1 = res->poses_scored;
+    unsigned steps2 = ransac_loop(q2, p, samples2, nsamples2, &st, &r2, best_mask, &kept);
+    if (kept) { *res = r2; if (best_leg) *best_leg = 1; }
+    res->poses_scored = scored1 + r2.poses_scored;
+    res->steps = steps + steps2;
+    return 1;
+}
+
+/* query_processor.cpp:46-86: p = P [X Y Z 1]^T, out2d = (p0/p2, p1/p2), out3d = (X, Y, Z). */
+void orc_project(const double P[12], int n, const float *X, const float *Y, const float *Z, double *out2d, double *out3d)
+{
+    for (int i = 0; i < n; ++i) {
+        double x = X[i], y = Y[i], z = Z[i];
+        double p0 = P[0] * x + P[1] * y + P[2] * z + P[3] * 1.0;
+        double p1 = P[4] * x + P[5] * y + P[6] * z + P[7] * 1.0;
+        double p2 = P[8] * x + P[9] * y + P[10] * z + P[11] * 1.0;
+        out2d[2 * i] = p0 / p2; out2d[2 * i + 1] = p1 / p2;
+        out3d[3 * i] = x; out3d[3 * i + 1] = y; out3d[3 * i + 2] = z;
+    }
 }
 
 uint64_t orc_ransac_fixed_budget(const orc_query *q, double eps, const uint32_t *samples, unsigned nsamples,

@@ -32,6 +32,8 @@ int orc_p3p_solve_quartic(const double factors[5], double roots[4]);
  * points).  sol: 4 blocks of 12 doubles: C[3] then Rc row-major[9] (cam->world).
  * Returns 0, or -1 when the world points are collinear (sol untouched). */
 int orc_p3p_compute_poses(const double fcols[9], const double pcols[9], double sol[48]);
+/* Same computation in long double, results rounded to double: the conditioning gate. */
+int orc_p3p_compute_poses_ld(const double fcols[9], const double pcols[9], double sol[48]);
 
 /* ---- P4Pf (P4pf.cpp) -------------------------------------------------------------- */
 #define ORC_P4PF_MAXSOL 10
@@ -57,6 +59,9 @@ void orc_compute_matrices(double focal, const double C[3], const double Rc[9], d
 int orc_score(const double P[12], int n, const float *kx, const float *ky, const float *X,
               const float *Y, const float *Z, int width, int height, double eps,
               uint8_t *mask);
+/* query_processor.cpp:46-86 (Project). out2d[2n] = (p0/p2, p1/p2) of p = P [X Y Z 1]^T,
+ * out3d[3n] = the world points as doubles. */
+void orc_project(const double P[12], int n, const float *X, const float *Y, const float *Z, double *out2d, double *out3d);
 /* query_processor.cpp:126-169. Union area of the coverage boxes of the selected
  * keypoints (mask==NULL: all). */
 int64_t orc_coverage_area(int n, const float *kx, const float *ky, const uint8_t *mask, int width,
@@ -106,6 +111,17 @@ typedef struct {
 /* samples: steps x 4 indices (explicit tuples; 3 used when focal != 0). */
 int orc_ransac(const orc_query *q, const orc_ransac_params *p, const uint32_t *samples,
                unsigned nsamples, orc_ransac_result *res, uint8_t *best_mask);
+
+/* The advanced processor's loop with its backmatching leg (query_processor_advanced.cpp:296-327,
+ * 583-606).  q1: good_matches before, q2: after Backmatching appended its matches (NULL: no
+ * backmatching available).  The second leg runs once, only if the kept pose of the first has
+ * fewer than min(n1 / inlier_divisor, inlier_absolute) inliers; steps restart, hyposet and
+ * hypoquality carry over.  res->best_step is relative to the leg that kept the pose
+ * (*best_leg = 0 / 1), res->steps the total.  best_mask: max(n1, n2) bytes.  Returns 1 if the
+ * second leg ran. */
+int orc_ransac_backmatch(const orc_query *q1, const orc_query *q2, const orc_ransac_params *p, const uint32_t *samples1,
+                         unsigned nsamples1, const uint32_t *samples2, unsigned nsamples2, orc_ransac_result *res,
+                         uint8_t *best_mask, int *best_leg);
 
 /* Fixed-budget throughput form for the CPU baseline: every sample is solved and every
  * returned pose scored against all correspondences (inlier-count selection, no early exit),

@@ -57,6 +57,8 @@ SIGNATURES = {
     "pose_amd_compute_matrices_batch": (C.c_int, [_ctx, C.c_int, _dp, _dp, _dp, _dp]),
     "pose_amd_score_batch": (C.c_int, [_ctx, C.c_int, _dp, C.c_double, _ip, _u64]),
     "pose_amd_coverage_batch": (C.c_int, [_ctx, C.c_int, _dp, C.c_double, _i64, _i64]),
+    "pose_amd_project_batch": (C.c_int, [_ctx, C.c_int, _dp, _dp, _dp]),
+    "pose_amd_best_fit": (C.c_int, [_ctx, _u8, _dp, _dp, _ip]),
     "pose_amd_sample": (C.c_int, [_ctx, C.c_int, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, _up]),
     "pose_amd_set_samples": (C.c_int, [_ctx, _up, C.c_uint32]),
     "pose_amd_ransac_run": (C.c_int, [_ctx, C.POINTER(Params), C.POINTER(Result), _ip, _ip]),

@@ -160,6 +160,24 @@ class Context:
                                                     C.byref(all_)), "coverage_batch")
         return areas, all_.value
 
+    def project_batch(self, P, want_3d=False):
+        """QueryProcessor::Project for each projection matrix: (nposes, n, 2) image points
+        [and the (n, 3) world points]."""
+        P = _f64(P).reshape(-1, 12)
+        p2 = np.zeros((len(P), self.n, 2))
+        p3 = np.zeros((self.n, 3)) if want_3d else None
+        self._chk(self._lib.pose_amd_project_batch(self._h, len(P), _ptr(P, _lib._dp), _ptr(p2, _lib._dp), _ptr(p3, _lib._dp)),
+                  "project_batch")
+        return (p2, p3) if want_3d else p2
+
+    def best_fit(self):
+        """Mask of the kept pose's fitted matches and their fitpoints_2d / fitpoints_3d."""
+        m = np.zeros(self.n, dtype=np.uint8)
+        f2 = np.zeros((self.n, 2)); f3 = np.zeros((self.n, 3))
+        k = C.c_int(0)
+        self._chk(self._lib.pose_amd_best_fit(self._h, _ptr(m, _lib._u8), _ptr(f2, _lib._dp), _ptr(f3, _lib._dp), C.byref(k)), "best_fit")
+        return m, f2[:k.value].copy(), f3[:k.value].copy()
+
     # ---- sampling ----------------------------------------------------------------------
     def sample(self, mode, seed, query_id, hyp_begin, hyp_count, export=True):
         out = np.zeros((hyp_count, 4), dtype=np.uint32) if export else None
@@ -353,6 +371,15 @@ class QueryProcessor:
         if q.cam_off is not None:
             self.ctx.set_camsets(q.cam_off, q.cam_ids)
 
+    def Project(self, query, matches=None):
+        """query_processor.cpp:46-86: (fitpoints_2d, fitpoints_3d) of query.proj_matrix() for the
+        matches selected by the boolean mask / index list `matches` (default: all)."""
+        self._upload(query)
+        p2, p3 = self.ctx.project_batch(query.proj_matrix(), want_3d=True)
+        if matches is None:
+            return p2[0], p3
+        return p2[0][matches], p3[matches]
+
     def TestHypothesis(self, query, match_eps=0.5):
         """Returns (inlier mask over the matches, fit_quality) for query.proj_matrix()."""
         self._upload(query)
@@ -395,7 +422,12 @@ class QueryProcessorBasic(QueryProcessor):
                 query.set_focal_length(r["focal"])
             query.set_camera_position(r["C"])
             query.set_camera_rotation(r["Rc"])
-            query.fitted_mask = self.ctx.best_mask().astype(bool)
+            # the final projection of the fitted matches (basic.cpp:296-307)
+            m, query.fitpoints_2d, query.fitpoints_3d = self.ctx.best_fit()
+            query.fitted_mask = m.astype(bool)
+        else:
+            query.fitted_mask = np.zeros(query.kx.size, bool)
+            query.fitpoints_2d, query.fitpoints_3d = np.zeros((0, 2)), np.zeros((0, 3))
         query.ComputeMatrices(self.ctx)
         return True
 
@@ -417,17 +449,25 @@ class QueryProcessorAdvanced(QueryProcessorBasic):
         self._upload(query)
         s1 = self.ctx.sample(self.sample_mode, self.seed, query_id, 0, self.max_ransac_steps)
         r = self.ctx.ransac_run(self.select_mode, self.inlier_eps, False, self.inlier_divisor, self.inlier_absolute)
-        best, mask, used = r, (self.ctx.best_mask() if r["found"] else None), [s1]
+        best, fit, used = r, (self.ctx.best_fit() if r["found"] else None), [s1]
+        # the size of good_matches before backmatching decides (advanced.cpp:587-589)
         thresh = min(query.kx.size // self.inlier_divisor, self.inlier_absolute)
         hyposet = r["inliers"] if r["found"] else 0
+        self.backmatched = False
         if self.backmatch is not None and hyposet < thresh:
             q2 = self.backmatch(query)
-            self._upload(q2)
+            self.backmatched = True
+            # Backmatching appends to good_matches in place (advanced.cpp:592): the caller's query
+            # takes over the extended match arrays, whichever leg keeps the pose
+            for k in ("kx", "ky", "X", "Y", "Z", "lindex", "cam_off", "cam_ids"):
+                setattr(query, k, getattr(q2, k))
+            self._upload(query)
             s2 = self.ctx.sample(self.sample_mode, self.seed, query_id, self.max_ransac_steps, self.max_ransac_steps)
             r2 = self.ctx.ransac_run(self.select_mode, self.inlier_eps, False, self.inlier_divisor, self.inlier_absolute)
             used.append(s2)
             # hypoquality is carried over while A_g changed (advanced.cpp:600-602): compare the
             # float ratios the reference compares
+            better = False
             if r2["found"]:
                 if self.select_mode == SELECT_COVERAGE:
                     q_old = np.float32(best["area_fit"]) / np.float32(best["area_all"]) if best["found"] else np.float32(0)
@@ -435,15 +475,27 @@ class QueryProcessorAdvanced(QueryProcessorBasic):
                     better = q_new > q_old
                 else:
                     better = r2["inliers"] > hyposet
-                if better:
-                    best, mask, query = r2, self.ctx.best_mask(), q2
+            if better:
+                best, fit = r2, self.ctx.best_fit()
+                self.best_leg = 1
+            else:
+                self.best_leg = 0
+                if fit is not None:       # fitted_matches of the first leg, indexed in the extended list
+                    m = np.zeros(query.kx.size, np.uint8)
+                    m[:len(fit[0])] = fit[0]
+                    fit = (m, fit[1], fit[2])
         self.samples = np.concatenate(used)
         self.steps = len(self.samples)
+        self.result = best
         if best["found"]:
             if query.focal_length() == 0.0:
                 query.set_focal_length(best["focal"])
             query.set_camera_position(best["C"])
             query.set_camera_rotation(best["Rc"])
-            query.fitted_mask = mask.astype(bool)
+            query.fitted_mask = fit[0].astype(bool)
+            query.fitpoints_2d, query.fitpoints_3d = fit[1], fit[2]
+        else:
+            query.fitted_mask = np.zeros(query.kx.size, bool)
+            query.fitpoints_2d, query.fitpoints_3d = np.zeros((0, 2)), np.zeros((0, 3))
         query.ComputeMatrices(self.ctx)
         return True

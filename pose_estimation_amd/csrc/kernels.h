@@ -522,6 +522,29 @@ __global__ void k_compute_matrices(int count, const double *__restrict__ focal, 
 }
 
 // ------------------------------------------------------------------------------------------
+// QueryProcessor::Project (query_processor.cpp:46-86) as an output of its own: the projected
+// image point of every correspondence for each of `nposes` projection matrices,
+// pts2d[(pose * n + i) * 2 + {0, 1}] = (p0 / p2, p1 / p2), and (pose 0 only, optional) the world
+// points as doubles.  The products are summed left to right without fused operations and the
+// quotients are IEEE divisions, the arithmetic of the reference's p = P * X; p / p(2).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_project(query_dev q, int nposes, const double *__restrict__ proj, double *__restrict__ pts2d,
+                                                 double *__restrict__ pts3d)
+{
+#pragma clang fp contract(off)                               // products and sums stay separate roundings, as in the reference's build
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, pose = blockIdx.y;
+    if (i >= q.n || pose >= nposes) return;
+    const double *__restrict__ P = proj + (size_t)pose * 12;
+    const double x = (double)q.X[i], y = (double)q.Y[i], z = (double)q.Z[i];
+    double p[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) p[r] = ((P[4 * r] * x + P[4 * r + 1] * y) + P[4 * r + 2] * z) + P[4 * r + 3];
+    double2 *o = reinterpret_cast<double2 *>(pts2d) + ((size_t)pose * q.n + i);
+    *o = make_double2(p[0] / p[2], p[1] / p[2]);
+    if (pts3d && pose == 0) { pts3d[3 * (size_t)i] = x; pts3d[3 * (size_t)i + 1] = y; pts3d[3 * (size_t)i + 2] = z; }
+}
+
+// ------------------------------------------------------------------------------------------
 // Scoring: QueryProcessor::Project + the inlier loop of TestHypothesis
 // (query_processor.cpp:46-124).
 //

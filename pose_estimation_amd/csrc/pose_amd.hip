@@ -22,6 +22,13 @@ struct dev_buf {
     void *p = nullptr;
     size_t cap = 0;
 };
+// page-locked host memory: the target of every device-to-host copy and the source of every
+// host-to-device copy the library issues, so that the copies are true asynchronous DMA
+// transfers and never go through the runtime's pageable staging path
+struct pin_buf {
+    void *p = nullptr;
+    size_t cap = 0;
+};
 } // namespace
 
 struct pose_amd_ctx {
@@ -56,12 +63,15 @@ struct pose_amd_ctx {
     void *qstage = nullptr;        // pinned staging copy of the same, so that a query is one host-to-device copy
     size_t qstage_cap = 0;
     uint32_t cam_max = 0;          // largest camera id of the current camera sets
-    std::vector<unsigned long long> band_host;   // per-band coverage sums as downloaded
+    pin_buf band_host;             // per-band coverage sums as downloaded
+    pin_buf h_nsol, h_counts, h_cand;   // coverage selection: per-chunk solution counts, inlier counts, candidate list
+    pin_buf h_words;               // small results: selection words + best pose (28 words), initial selection words, pose downloads
+    int distinct_lindex = 0;       // distinct keypoint indices of the query, capped at 4 (the samplers need that many)
     bool sel_armed = false;        // sel[0..2] hold the initial values of a selection
     bool sel_fused = false;        // the last scoring launch of the chunk also did the inlier-count selection
     bool timing = true;            // record per-kernel timing events (off for the batch entry point's worker contexts:
                                    // every event is one more command for the GPU's command processor)
-    // batch entry point: child contexts (one stream each) and their pinned result words
+    // batch entry point: child contexts (one stream each)
     std::vector<pose_amd_ctx *> lanes;
     // hypotheses
     uint32_t hyp_count = 0;
@@ -97,6 +107,16 @@ static int ensure(pose_amd_ctx *ctx, dev_buf &b, size_t bytes)
     if (b.p) { HIPCHK(ctx, hipFree(b.p)); b.p = nullptr; b.cap = 0; }
     size_t want = bytes + bytes / 8 + 256;
     HIPCHK(ctx, hipMalloc(&b.p, want));
+    b.cap = want;
+    return POSE_AMD_OK;
+}
+
+static int ensure_pinned(pose_amd_ctx *ctx, pin_buf &b, size_t bytes)
+{
+    if (bytes <= b.cap) return POSE_AMD_OK;
+    if (b.p) { HIPCHK(ctx, hipHostFree(b.p)); b.p = nullptr; b.cap = 0; }
+    size_t want = bytes + bytes / 4 + 256;
+    HIPCHK(ctx, hipHostMalloc(&b.p, want, hipHostMallocDefault));
     b.cap = want;
     return POSE_AMD_OK;
 }
@@ -209,6 +229,8 @@ int pose_amd_create(int device, pose_amd_ctx **out)
     if (hipMalloc(&c->gain.p, gain.size() * sizeof(double)) != hipSuccess) return bail("hipMalloc", hipErrorOutOfMemory);
     c->gain.cap = gain.size() * sizeof(double);
     if ((e = hipMemcpy(c->gain.p, gain.data(), c->gain.cap, hipMemcpyHostToDevice)) != hipSuccess) return bail("hipMemcpy", e);
+    if ((e = hipHostMalloc(&c->h_words.p, 64 * 8, hipHostMallocDefault)) != hipSuccess) return bail("hipHostMalloc", e);
+    c->h_words.cap = 64 * 8;
     *out = c;
     return POSE_AMD_OK;
 }
@@ -223,6 +245,8 @@ void pose_amd_destroy(pose_amd_ctx *c)
                        &c->maskw, &c->arows, &c->pstatus, &c->projf, &c->feat, &c->vlist, &c->vcount, &c->arows2, &c->pstatus2, &c->vlist2, &c->vcount2, &c->in0, &c->in1, &c->in2, &c->out0, &c->out1, &c->out2, &c->out3};
     for (dev_buf *b : bufs) if (b->p) (void)hipFree(b->p);
     if (c->qstage) (void)hipHostFree(c->qstage);
+    pin_buf *pins[] = {&c->band_host, &c->h_nsol, &c->h_counts, &c->h_cand, &c->h_words};
+    for (pin_buf *b : pins) if (b->p) (void)hipHostFree(b->p);
     for (int i = 0; i < 6; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
     for (int i = 0; i < 6; ++i) if (c->ev2[i]) (void)hipEventDestroy(c->ev2[i]);
     if (c->stream2) { (void)hipStreamSynchronize(c->stream2); (void)hipStreamDestroy(c->stream2); }
@@ -358,6 +382,20 @@ int pose_amd_set_query(pose_amd_ctx *ctx, int n, const float *kx, const float *k
         dm = std::fmax(dm, std::fmax(std::fabs((double)X[i] - cx), std::fmax(std::fabs((double)Y[i] - cy), std::fabs((double)Z[i] - cz))));
     const bool cfin = finite && std::isfinite(cx) && std::isfinite(cy) && std::isfinite(cz) && std::isfinite(dm);
     ctx->centre = query_centre{cx, cy, cz, cfin ? (float)(dm * 1.000001) : NAN};
+    // The samplers redraw a pick while its keypoint index equals that of an earlier pick
+    // (basic.cpp:136-152): with fewer distinct indices than picks that loop would never end.
+    if (lindex) {
+        uint32_t seen[4];
+        int ns = 0;
+        for (int i = 0; i < n && ns < 4; ++i) {
+            bool dup = false;
+            for (int j = 0; j < ns; ++j) dup = dup || seen[j] == lindex[i];
+            if (!dup) seen[ns++] = lindex[i];
+        }
+        ctx->distinct_lindex = ns;
+    } else {
+        ctx->distinct_lindex = std::min(n, 4);
+    }
     ctx->feat_ready = false;
     ctx->solver = focal == 0.0 ? POSE_AMD_SOLVER_P4PF : POSE_AMD_SOLVER_P3P;
     ctx->has_cam = false;
@@ -371,7 +409,8 @@ int pose_amd_set_query(pose_amd_ctx *ctx, int n, const float *kx, const float *k
 
 int pose_amd_set_camsets(pose_amd_ctx *ctx, const uint32_t *cam_off, const uint32_t *cam_ids)
 {
-    if (!ctx || !cam_off || ctx->n <= 0) return fail(ctx, POSE_AMD_EINVAL, "set_camsets: no query or bad argument");
+    if (!ctx || !cam_off || !cam_ids || ctx->n <= 0) return fail(ctx, POSE_AMD_EINVAL, "set_camsets: no query or bad argument");
+    if (cam_off[0] != 0) return fail(ctx, POSE_AMD_EINVAL, "set_camsets: cam_off[0] must be 0");
     bool any5 = false;
     uint32_t cam_max = 0;
     for (int i = 0; i < ctx->n; ++i) {
@@ -576,13 +615,14 @@ static int coverage_dev(pose_amd_ctx *ctx, int nposes, const double *proj_dev, d
         HIPCHK(ctx, hipGetLastError());
         p0 += pt.cn;
     }
-    ctx->band_host.resize(total);
-    if ((rc = download(ctx, ctx->band_host.data(), ctx->areas.p, total * 8)) || (rc = pose_amd_synchronize(ctx))) return rc;
+    if ((rc = ensure_pinned(ctx, ctx->band_host, total * 8))) return rc;
+    const unsigned long long *band_host = (const unsigned long long *)ctx->band_host.p;
+    if ((rc = download(ctx, ctx->band_host.p, ctx->areas.p, total * 8)) || (rc = pose_amd_synchronize(ctx))) return rc;
     p0 = 0;
     for (const part &pt : parts) {
         for (int i = 0; i < pt.cn; ++i) {
             int64_t a = 0;
-            for (int b = 0; b < pt.bands; ++b) a += (int64_t)ctx->band_host[pt.off + (size_t)i * pt.bands + b];
+            for (int b = 0; b < pt.bands; ++b) a += (int64_t)band_host[pt.off + (size_t)i * pt.bands + b];
             areas_host[p0 + i] = a;
         }
         p0 += pt.cn;
@@ -608,6 +648,26 @@ int pose_amd_coverage_batch(pose_amd_ctx *ctx, int nposes, const double *P, doub
     return POSE_AMD_OK;
 }
 
+int pose_amd_project_batch(pose_amd_ctx *ctx, int nposes, const double *P, double *pts2d, double *pts3d)
+{
+    if (!ctx || nposes < 0 || (nposes && (!P || !pts2d))) return fail(ctx, POSE_AMD_EINVAL, "project_batch: bad argument");
+    if (ctx->n <= 0) return fail(ctx, POSE_AMD_ESTATE, "project_batch: no query set");
+    if (nposes == 0) return POSE_AMD_OK;
+    if (nposes > 65535) return fail(ctx, POSE_AMD_EINVAL, "project_batch: more than 65535 poses in one call");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    int rc;
+    const size_t n = (size_t)ctx->n;
+    if ((rc = upload(ctx, ctx->in0, P, (size_t)nposes * 96)) || (rc = ensure(ctx, ctx->out0, (size_t)nposes * n * 16)) ||
+        (pts3d && (rc = ensure(ctx, ctx->out1, n * 24))))
+        return rc;
+    hipLaunchKernelGGL(k_project, dim3(cdiv((long long)n, 256), nposes), dim3(256), 0, ctx->stream, make_query(ctx), nposes,
+                       (const double *)ctx->in0.p, (double *)ctx->out0.p, pts3d ? (double *)ctx->out1.p : nullptr);
+    HIPCHK(ctx, hipGetLastError());
+    if ((rc = download(ctx, pts2d, ctx->out0.p, (size_t)nposes * n * 16))) return rc;
+    if (pts3d && (rc = download(ctx, pts3d, ctx->out1.p, n * 24))) return rc;
+    return pose_amd_synchronize(ctx);
+}
+
 // ---- sampling -----------------------------------------------------------------------------------
 int pose_amd_sample(pose_amd_ctx *ctx, int sample_mode, uint64_t seed, uint32_t query_id, uint32_t hyp_begin, uint32_t hyp_count,
                     uint32_t *samples_out)
@@ -617,7 +677,8 @@ int pose_amd_sample(pose_amd_ctx *ctx, int sample_mode, uint64_t seed, uint32_t 
     const int m = ctx->solver == POSE_AMD_SOLVER_P4PF ? 4 : 3;
     // The reference loops forever when fewer distinct keypoints exist than picks
     // (GetRandomSelector on a too-small set, basic.cpp:136-152); refuse instead.
-    if (ctx->n < m) return fail(ctx, POSE_AMD_EINVAL, "sample: fewer correspondences than the minimal sample size");
+    if (ctx->n < m || ctx->distinct_lindex < m)
+        return fail(ctx, POSE_AMD_EINVAL, "sample: fewer correspondences (distinct keypoints) than the minimal sample size");
     if (sample_mode != POSE_AMD_SAMPLE_BASIC && sample_mode != POSE_AMD_SAMPLE_ADVANCED) return fail(ctx, POSE_AMD_EINVAL, "sample: bad mode");
     if (sample_mode == POSE_AMD_SAMPLE_ADVANCED && !ctx->has_cam) return fail(ctx, POSE_AMD_ESTATE, "sample: advanced mode needs camera sets");
     ctx->hyp_count = 0;
@@ -674,9 +735,9 @@ static int arm_select(pose_amd_ctx *ctx)
     int rc;
     if ((rc = ensure(ctx, ctx->sel, 31 * 8))) return rc;
     if (!ctx->sel_armed) {
-        const unsigned long long init[3] = {0ull, ~0ull, 0ull};
+        unsigned long long *init = (unsigned long long *)ctx->h_words.p + 28;   // page-locked, never rewritten with other values
+        init[0] = 0ull; init[1] = ~0ull; init[2] = 0ull;
         HIPCHK(ctx, hipMemcpyAsync(ctx->sel.p, init, 24, hipMemcpyHostToDevice, ctx->stream));
-        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));      // init is a stack array
         ctx->sel_armed = true;                               // k_gather_best re-arms it after every selection
     }
     return POSE_AMD_OK;
@@ -696,7 +757,7 @@ static int run_select(pose_amd_ctx *ctx, int limit, int maxsol, unsigned thresh,
     hipLaunchKernelGGL(k_gather_best, dim3(1), dim3(64), 0, ctx->stream, (unsigned long long *)ctx->sel.p, (const double *)ctx->pose.p,
                        (const double *)ctx->proj.p);
     HIPCHK(ctx, hipGetLastError());
-    unsigned long long host[28];
+    unsigned long long *host = (unsigned long long *)ctx->h_words.p;
     if ((rc = download(ctx, host, (const char *)ctx->sel.p + 24, 28 * 8)) || (rc = pose_amd_synchronize(ctx))) return rc;
     memcpy(out, host, 24);
     if (host[2] != 0ull) memcpy(best, host + 3, 25 * 8);
@@ -774,7 +835,11 @@ int pose_amd_ransac_run(pose_amd_ctx *ctx, const pose_amd_params *prm, pose_amd_
     memset(ctx->last_ms, 0, sizeof ctx->last_ms);
     const uint32_t H = ctx->hyp_count;
     const unsigned thresh_u = std::min((unsigned)ctx->n / prm->inlier_divisor, (unsigned)prm->inlier_absolute);
-    if (H == 0 || (prm->early_exit && thresh_u == 0)) return POSE_AMD_OK;   // the reference's loop body never runs
+    if (H == 0 || (prm->early_exit && thresh_u == 0)) {                    // the reference's loop body never runs
+        // worker contexts of the batch entry point have the query's upload (and the sample kernel)
+        // still in flight; the staging buffer is rewritten for the next query after this call
+        return ctx->lazy_sync ? pose_amd_synchronize(ctx) : POSE_AMD_OK;
+    }
     HIPCHK(ctx, hipSetDevice(ctx->device));
     const int maxsol = ctx->solver == POSE_AMD_SOLVER_P4PF ? P4PF_MAXSOL : P3P_MAXSOL;
     // Hypotheses are evaluated speculatively in chunks; the selection below replays them in
@@ -807,7 +872,6 @@ int pose_amd_ransac_run(pose_amd_ctx *ctx, const pose_amd_params *prm, pose_amd_
     uint64_t poses_scored = 0;
     double best_pose[13];
     bool done = false;
-    std::vector<int> h_nsol, h_counts, cand;
     std::vector<int64_t> areas;
 
     for (uint32_t h0 = 0, hc = 0; h0 < H && !done; h0 += hc) {
@@ -835,9 +899,13 @@ int pose_amd_ransac_run(pose_amd_ctx *ctx, const pose_amd_params *prm, pose_amd_
         } else {
             // Coverage quality q = A_f / A_g (query_processor.cpp:171-174).  A_g is fixed for the
             // query, so q1 > q2 <=> A_f1 > A_f2, and A_f <= count * box prunes poses that cannot win.
-            h_nsol.resize(hc); h_counts.resize(nslots);
-            if ((rc = download(ctx, h_nsol.data(), ctx->nsol.p, (size_t)hc * 4)) ||
-                (rc = download(ctx, h_counts.data(), ctx->counts.p, nslots * 4)) || (rc = pose_amd_synchronize(ctx)))
+            if ((rc = ensure_pinned(ctx, ctx->h_nsol, (size_t)hc * 4)) || (rc = ensure_pinned(ctx, ctx->h_counts, nslots * 4)) ||
+                (rc = ensure_pinned(ctx, ctx->h_cand, 4096 * 4)))
+                return rc;
+            const int *h_nsol = (const int *)ctx->h_nsol.p, *h_counts = (const int *)ctx->h_counts.p;
+            int *cand = (int *)ctx->h_cand.p;
+            if ((rc = download(ctx, ctx->h_nsol.p, ctx->nsol.p, (size_t)hc * 4)) ||
+                (rc = download(ctx, ctx->h_counts.p, ctx->counts.p, nslots * 4)) || (rc = pose_amd_synchronize(ctx)))
                 return rc;
             // candidates are evaluated speculatively in batches; the first batch is small (it
             // usually raises the pruning bound a lot), later ones grow so that a chunk full of
@@ -845,17 +913,18 @@ int pose_amd_ransac_run(pose_amd_ctx *ctx, const pose_amd_params *prm, pose_amd_
             int BATCH = 256;
             size_t s = 0;
             while (!done && s < nslots) {
-                cand.clear();
+                size_t ncand = 0;
                 areas.resize((size_t)BATCH);
                 size_t scan = s;
-                while (scan < nslots && (int)cand.size() < BATCH) {
+                while (scan < nslots && (int)ncand < BATCH) {
                     const uint32_t h = (uint32_t)(scan / maxsol), k = (uint32_t)(scan % maxsol);
-                    if ((int)k < h_nsol[h] && h_counts[scan] > 0 && (long long)h_counts[scan] * box > best_area) cand.push_back((int)scan);
+                    if ((int)k < h_nsol[h] && h_counts[scan] > 0 && (long long)h_counts[scan] * box > best_area) cand[ncand++] = (int)scan;
                     ++scan;
                 }
-                if (!cand.empty()) {
-                    if ((rc = upload(ctx, ctx->in0, cand.data(), cand.size() * 4))) return rc;
-                    if ((rc = coverage_dev(ctx, (int)cand.size(), (const double *)ctx->proj.p, prm->eps, 0, areas.data(),
+                if (ncand) {
+                    // coverage_dev synchronises before it returns, so the list may be rewritten afterwards
+                    if ((rc = upload(ctx, ctx->in0, cand, ncand * 4))) return rc;
+                    if ((rc = coverage_dev(ctx, (int)ncand, (const double *)ctx->proj.p, prm->eps, 0, areas.data(),
                                            (const int *)ctx->in0.p)))
                         return rc;
                 }
@@ -864,7 +933,7 @@ int pose_amd_ransac_run(pose_amd_ctx *ctx, const pose_amd_params *prm, pose_amd_
                     const uint32_t h = (uint32_t)(t / maxsol), k = (uint32_t)(t % maxsol);
                     if (k == 0 && prm->early_exit && best_count >= thresh_u) { chunk_steps = h; done = true; break; }
                     if ((int)k < h_nsol[h]) ++poses_scored;
-                    if (ci < cand.size() && (size_t)cand[ci] == t) {
+                    if (ci < ncand && (size_t)cand[ci] == t) {
                         const int64_t a = areas[ci++];
                         if (a > best_area) { best_area = a; best_count = (uint32_t)h_counts[t]; chunk_best = (long long)t; }
                     }
@@ -902,10 +971,13 @@ int pose_amd_ransac_run(pose_amd_ctx *ctx, const pose_amd_params *prm, pose_amd_
             memcpy(ctx->best_proj, gathered + 13, 96);
         } else if (chunk_best >= 0) {
             best_slot = (long long)h0 * maxsol + chunk_best;
-            if ((rc = download(ctx, best_pose, (const char *)ctx->pose.p + (size_t)chunk_best * 104, 104)) ||
-                (rc = download(ctx, ctx->best_proj, (const char *)ctx->proj.p + (size_t)chunk_best * 96, 96)) ||
+            double *hp = (double *)ctx->h_words.p + 32;
+            if ((rc = download(ctx, hp, (const char *)ctx->pose.p + (size_t)chunk_best * 104, 104)) ||
+                (rc = download(ctx, hp + 16, (const char *)ctx->proj.p + (size_t)chunk_best * 96, 96)) ||
                 (rc = pose_amd_synchronize(ctx)))
                 return rc;
+            memcpy(best_pose, hp, 104);
+            memcpy(ctx->best_proj, hp + 16, 96);
         }
         if (nsol_out && (rc = download(ctx, nsol_out + h0, ctx->nsol.p, (size_t)hc * 4))) return rc;
         if (counts_out && (rc = download(ctx, counts_out + (size_t)h0 * maxsol, ctx->counts.p, nslots * 4))) return rc;
@@ -987,6 +1059,27 @@ int pose_amd_best_mask(pose_amd_ctx *ctx, uint8_t *mask)
     int rc = pose_amd_score_batch(ctx, 1, ctx->best_proj, ctx->last_eps, &cnt, words.data());
     if (rc) return rc;
     for (int i = 0; i < ctx->n; ++i) mask[i] = (uint8_t)((words[(size_t)i >> 6] >> (i & 63)) & 1u);
+    return POSE_AMD_OK;
+}
+
+int pose_amd_best_fit(pose_amd_ctx *ctx, uint8_t *mask, double *fit2d, double *fit3d, int *nfit)
+{
+    if (!ctx || !fit2d || !fit3d || !nfit) return fail(ctx, POSE_AMD_EINVAL, "best_fit: bad argument");
+    if (!ctx->have_best) return fail(ctx, POSE_AMD_ESTATE, "best_fit: no kept pose");
+    const size_t n = (size_t)ctx->n;
+    std::vector<uint8_t> m(n);
+    std::vector<double> p2(2 * n), p3(3 * n);
+    int rc;
+    if ((rc = pose_amd_best_mask(ctx, m.data())) || (rc = pose_amd_project_batch(ctx, 1, ctx->best_proj, p2.data(), p3.data()))) return rc;
+    int k = 0;
+    for (size_t i = 0; i < n; ++i) {
+        if (!m[i]) continue;
+        fit2d[2 * k] = p2[2 * i]; fit2d[2 * k + 1] = p2[2 * i + 1];
+        fit3d[3 * k] = p3[3 * i]; fit3d[3 * k + 1] = p3[3 * i + 1]; fit3d[3 * k + 2] = p3[3 * i + 2];
+        ++k;
+    }
+    *nfit = k;
+    if (mask) memcpy(mask, m.data(), n);
     return POSE_AMD_OK;
 }
 

@@ -422,17 +422,20 @@ __global__ __launch_bounds__(MS_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
         for (int i = tid; i < nblk; i += MS_THREADS) counts[s_slot[i]] = s_cnt[i];
         if (sel) publish_best(s_cnt[tid]);
     } else {
-        // The adds are device-scope atomics, performed where all compute dies see them; taking
-        // their return values makes the thread wait until that has happened, so that the counter
-        // below orders the blocks without a release fence (which would write back the L2).
+        // The counts of a pose are added up by device-scope atomics from the blocks that share it.
         for (int i = tid; i < nblk; i += MS_THREADS)
-            if (s_cnt[i]) { const int before = atomicAdd(&counts[s_slot[i]], s_cnt[i]); asm volatile("" :: "v"(before)); }
+            if (s_cnt[i]) atomicAdd(&counts[s_slot[i]], s_cnt[i]);
         if (sel) {
             // the block that finishes last among those that share these poses (nvalid_p[2 + x]
-            // counts them and is left at zero again) reads the summed counts and publishes
+            // counts them and is left at zero again) reads the summed counts and publishes.
+            // Ordering: the barrier orders the block's adds before thread 0's increment of the
+            // group's counter, which is a release (this block's adds are visible to whoever reads
+            // the counter) and an acquire (the last block sees the adds of all earlier ones) at
+            // device scope; the second barrier hands that on to the block's other threads.
             unsigned int *batch_done = nvalid_p + 2;
             __syncthreads();
-            if (tid == 0) s_dense[0] = atomicAdd(&batch_done[blockIdx.x], 1u) == gridDim.y - 1 ? 1 : 0;   // s_dense is free by now
+            if (tid == 0)
+                s_dense[0] = __hip_atomic_fetch_add(&batch_done[blockIdx.x], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.y - 1 ? 1 : 0;   // s_dense is free by now
             __syncthreads();
             if (s_dense[0]) {
                 if (tid == 0) __hip_atomic_store(&batch_done[blockIdx.x], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

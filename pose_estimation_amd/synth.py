@@ -72,7 +72,49 @@ def add_camsets(q, seed, n_cams=6000, cluster=12):
         off.append(off[-1] + k)
     q["cam_off"] = np.array(off, dtype=np.uint32)
     q["cam_ids"] = np.concatenate(ids).astype(np.uint32)
+    q["cam_common"], q["cam_total"] = common, n_cams
     return q
+
+
+def append_matches(q, extra, inlier_frac, seed, noise_px=0.3, many_cams_frac=0.25):
+    """What a backmatching pass does to good_matches (query_processor_advanced.cpp:592): a copy of
+    the query with `extra` matches appended, a fraction of them consistent with the planted pose
+    (camera sets included when the query has them).  The original matches keep their positions."""
+    rng = np.random.default_rng(seed)
+    w, h, f = q["width"], q["height"], q["f_true"]
+    Rc, Cc = q["Rc_true"], q["C_true"]
+    n_in = int(round(extra * inlier_frac))
+    z = rng.uniform(10.0, 200.0, extra)
+    u = rng.uniform(-w / 2 + 1, w / 2 - 1, extra)
+    v = rng.uniform(-h / 2 + 1, h / 2 - 1, extra)
+    Xw = (np.stack([u * z / f, v * z / f, z], 1) @ Rc.T + Cc).astype(np.float32)
+    Xc32 = (Xw.astype(np.float64) - Cc) @ Rc
+    up, vp = f * Xc32[:, 0] / Xc32[:, 2], f * Xc32[:, 1] / Xc32[:, 2]
+    is_in = np.zeros(extra, dtype=bool)
+    is_in[rng.permutation(extra)[:n_in]] = True
+    r = noise_px * np.sqrt(rng.uniform(0, 1, extra))
+    ang = rng.uniform(0, 2 * np.pi, extra)
+    uo = np.where(is_in, up + r * np.cos(ang), rng.uniform(-w / 2 + 1, w / 2 - 1, extra))
+    vo = np.where(is_in, vp + r * np.sin(ang), rng.uniform(-h / 2 + 1, h / 2 - 1, extra))
+    out = dict(q)
+    out["kx"] = np.concatenate([q["kx"], (w / 2.0 - uo).astype(np.float32)])
+    out["ky"] = np.concatenate([q["ky"], (h / 2.0 - vo).astype(np.float32)])
+    for k, col in (("X", 0), ("Y", 1), ("Z", 2)):
+        out[k] = np.concatenate([q[k], Xw[:, col]])
+    out["inliers"] = np.concatenate([q["inliers"], is_in])
+    if "cam_off" in q:
+        off, ids = list(q["cam_off"]), [q["cam_ids"]]
+        for i in range(extra):
+            pool = q["cam_common"] if is_in[i] else np.arange(q["cam_total"])
+            k = int(rng.integers(2, 5))
+            if rng.uniform() < many_cams_frac:         # seen by >= 5 cameras: can start a tuple (advanced.cpp:350-359)
+                k = int(rng.integers(5, 9))
+            k = min(k, len(pool))
+            ids.append(np.sort(rng.choice(pool, k, replace=False)).astype(np.uint32))
+            off.append(off[-1] + k)
+        out["cam_off"] = np.array(off, dtype=np.uint32)
+        out["cam_ids"] = np.concatenate(ids).astype(np.uint32)
+    return out
 
 
 def random_p4pf_problems(count, seed, contaminate=(0, 1, 2), noise=0.3):

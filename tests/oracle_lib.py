@@ -39,6 +39,11 @@ def load():
     lib = C.CDLL(_SO)
     lib.orc_p3p_solve_quartic.argtypes = [_dp, _dp]
     lib.orc_p3p_compute_poses.argtypes = [_dp, _dp, _dp]
+    lib.orc_p3p_compute_poses_ld.argtypes = [_dp, _dp, _dp]
+    lib.orc_project.argtypes = [_dp, C.c_int, _fp, _fp, _fp, _dp, _dp]
+    lib.orc_project.restype = None
+    lib.orc_ransac_backmatch.argtypes = [C.POINTER(OrcQuery), C.POINTER(OrcQuery), C.POINTER(OrcParams), _up, C.c_uint, _up, C.c_uint,
+                                         C.POINTER(OrcResult), _bp, C.POINTER(C.c_int)]
     lib.orc_p4pf.argtypes = [_dp] * 5
     lib.orc_p4pf_ld.argtypes = [_dp] * 5
     lib.orc_p4pf_stages.argtypes = [_dp] * 5
@@ -77,12 +82,13 @@ def solve_quartic(factors):
     return r
 
 
-def p3p(fcols, pcols):
+def p3p(fcols, pcols, long_double=False):
     """fcols/pcols: (3,3) arrays whose ROWS are the three vectors. Returns (status, C[4,3], Rc[4,3,3])."""
     f = np.ascontiguousarray(fcols, dtype=np.float64)
     p = np.ascontiguousarray(pcols, dtype=np.float64)
     sol = np.full(48, np.nan)
-    st = lib().orc_p3p_compute_poses(_p(f, _dp), _p(p, _dp), _p(sol, _dp))
+    fn = lib().orc_p3p_compute_poses_ld if long_double else lib().orc_p3p_compute_poses
+    st = fn(_p(f, _dp), _p(p, _dp), _p(sol, _dp))
     sol = sol.reshape(4, 12)
     return st, sol[:, :3].copy(), sol[:, 3:].reshape(4, 3, 3).copy()
 
@@ -120,6 +126,15 @@ def score(P, kx, ky, X, Y, Z, width, height, eps=0.5):
     cnt = lib().orc_score(_p(P, _dp), n, _p(kx, _fp), _p(ky, _fp), _p(X, _fp), _p(Y, _fp), _p(Z, _fp), width, height,
                           eps, _p(mask, _bp))
     return cnt, mask
+
+
+def project(P, X, Y, Z):
+    """QueryProcessor::Project: (n,2) projected points and (n,3) world points."""
+    P = np.ascontiguousarray(P, dtype=np.float64)
+    n = len(X)
+    o2 = np.zeros((n, 2)); o3 = np.zeros((n, 3))
+    lib().orc_project(_p(P, _dp), n, _p(X, _fp), _p(Y, _fp), _p(Z, _fp), _p(o2, _dp), _p(o3, _dp))
+    return o2, o3
 
 
 def coverage_area(kx, ky, mask, width, height):
@@ -163,6 +178,35 @@ def ransac(kx, ky, X, Y, Z, width, height, focal, samples, select_coverage=True,
                best_step=res.best_step, best_sol=res.best_sol, poses_scored=res.poses_scored)
     if want_mask:
         out["mask"] = mask
+    return out
+
+
+def _result_dict(res):
+    return dict(found=res.found, focal=res.focal, C=np.array(res.C[:]), Rc=np.array(res.Rc[:]).reshape(3, 3),
+                hyposet=res.hyposet, area_fit=res.area_fit, area_all=res.area_all, steps=res.steps,
+                best_step=res.best_step, best_sol=res.best_sol, poses_scored=res.poses_scored)
+
+
+def ransac_backmatch(q1, q2, samples1, samples2, select_coverage=True, eps=0.5, max_steps=100, early_exit=False):
+    """The advanced processor's loop with its backmatching leg.  q1 / q2: dicts with kx, ky, X, Y, Z,
+    width, height, focal (q2 = the matches after backmatching, or None).  Returns the result dict
+    plus second_leg (did it run), best_leg (which leg kept the pose) and mask (of that leg's matches)."""
+    def mk(q):
+        arrs = [np.ascontiguousarray(q[k], dtype=np.float32) for k in ("kx", "ky", "X", "Y", "Z")]
+        return OrcQuery(len(arrs[0]), *[_p(a, _fp) for a in arrs], q["width"], q["height"], float(q["focal"])), arrs
+    o1, keep1 = mk(q1)
+    o2, keep2 = mk(q2) if q2 is not None else (None, None)
+    p = OrcParams(int(select_coverage), eps, max_steps, 10, 12, int(early_exit))
+    s1 = np.ascontiguousarray(samples1, dtype=np.uint32)
+    s2 = np.ascontiguousarray(samples2, dtype=np.uint32) if samples2 is not None else np.zeros((0, 4), np.uint32)
+    res = OrcResult()
+    nmax = max(o1.n, o2.n if o2 is not None else 0)
+    mask = np.zeros(nmax, dtype=np.uint8)
+    leg = C.c_int(0)
+    second = lib().orc_ransac_backmatch(C.byref(o1), C.byref(o2) if o2 is not None else None, C.byref(p), _p(s1, _up), len(s1),
+                                        _p(s2, _up), len(s2), C.byref(res), _p(mask, _bp), C.byref(leg))
+    out = _result_dict(res)
+    out.update(second_leg=bool(second), best_leg=leg.value, mask=mask[:(o2.n if leg.value == 1 else o1.n)])
     return out
 
 

@@ -1,0 +1,210 @@
+"""GPU parity tests of whole configurations against the CPU oracle: the Dubrovnik-shaped batch
+through pose_amd_ransac_batch in the reference's mode (coverage quality, early exit), the
+advanced processor including its backmatching leg, and the Project outputs.
+
+Bars: steps, kept hypothesis, inlier counts and coverage areas bit-exact; poses within
+max(1e-8, 20 e_ref) relative, e_ref being the double oracle's distance from its long-double
+self on the kept sample (the conditioning gate); projected points within 1e-12 relative."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from pose_estimation_amd import synth, SELECT_COVERAGE, SELECT_INLIERS, SAMPLE_BASIC, SAMPLE_ADVANCED
+from pose_estimation_amd import Query, QueryProcessor, QueryProcessorBasic, QueryProcessorAdvanced
+from gates import pose_tolerance, relerr, RTOL
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def oracle_args(q):
+    return (q["kx"], q["ky"], q["X"], q["Y"], q["Z"], q["width"], q["height"], q["focal"])
+
+
+def assert_pose_close(q, sample, got, exp):
+    """got / exp: dicts with focal, C, Rc of the same (hypothesis, solution)."""
+    tol = pose_tolerance(q, sample)
+    if tol is None:                          # the two oracles disagree on this sample: ungated
+        return False
+    assert relerr(got["C"], exp["C"], 1e-3) < tol and relerr(got["Rc"], exp["Rc"], 1e-3) < tol, (tol, got["C"], exp["C"])
+    assert abs(got["focal"] - exp["focal"]) <= tol * abs(exp["focal"])
+    return True
+
+
+# ---- BASELINE configs[2]: Dubrovnik-shaped batch, reference mode ---------------------------------
+def dubrovnik_queries():
+    with open(os.path.join(GOLD, "dubrovnik_queries.json")) as f:
+        shapes = json.load(f)["queries"]
+    # 1600x1066 known, 1200x1600 unknown and known, 1600x1200 unknown and known, 1024x768 unknown,
+    # 486x648 known, 1200x800 known, 1066x1600 (first of that shape), 1600x1064
+    picks = [5, 8, 27, 21, 24, 2, 0, 1]
+    picks += [next(i for i, s in enumerate(shapes) if (s[0], s[1]) == wh) for wh in ((1066, 1600), (1600, 1064))]
+    rng = np.random.default_rng(2024)
+    out = []
+    for k, qi in enumerate(picks):
+        w, h, f = shapes[qi]
+        n = int(rng.integers(4000, 6001))
+        frac = float(rng.uniform(0.12, 0.40)) if k else 0.10
+        q = synth.make_query(n, frac, 3000 + qi, width=w, height=h, focal=f if f > 0 else 0.9 * max(w, h), known_focal=f > 0)
+        q["query_id"] = qi
+        out.append(q)
+    return out
+
+
+def test_dubrovnik_batch_reference_mode_equals_oracle(ctx):
+    """Ten entries of the committed Dubrovnik fixture (image sizes and known / unknown focal lengths
+    of the real query list, 4 000-6 000 matches) through the multi-query entry point with the
+    reference's loop: every query's steps, kept hypothesis, inliers and coverage areas equal the
+    oracle's on the exported tuples, poses within the gated bar."""
+    queries = dubrovnik_queries()
+    assert {(q["width"], q["height"]) for q in queries} >= {(1600, 1066), (1200, 1600), (1600, 1200)}
+    assert any(q["focal"] > 0 for q in queries) and any(q["focal"] == 0 for q in queries)
+    assert all(4000 <= len(q["kx"]) <= 6000 for q in queries)
+    budget, seed = 10000, 3000
+    got = ctx.ransac_batch(queries, SAMPLE_BASIC, seed=seed, budget=budget, select_mode=SELECT_COVERAGE, early_exit=True)
+    gated = 0
+    for q, g in zip(queries, got):
+        ctx.set_query(*oracle_args(q))
+        samples = ctx.sample(SAMPLE_BASIC, seed, q["query_id"], 0, budget)
+        m = 4 if q["focal"] == 0 else 3
+        for h in (0, 1, 17, budget - 1):
+            assert np.array_equal(samples[h, :m], O.sample_basic(seed, q["query_id"], h, m, len(q["kx"]))[0][:m])
+        s = samples.copy()
+        s[:, 3] = np.where(s[:, 3] == 0xFFFFFFFF, 0, s[:, 3])
+        o = O.ransac(*oracle_args(q), s, select_coverage=True, early_exit=True, max_steps=budget)
+        key = (q["width"], q["height"], q["focal"], len(q["kx"]))
+        assert (g["found"], g["steps"]) == (o["found"], o["steps"]), key
+        assert g["area_all"] == o["area_all"], key
+        if not o["found"]:
+            continue
+        assert (g["best_hyp"], g["inliers"], g["area_fit"]) == (o["best_step"], o["hyposet"], o["area_fit"]), key
+        assert g["inliers"] >= 12 or g["steps"] == budget
+        if g["best_sol"] == o["best_sol"]:
+            gated += assert_pose_close(q, s[g["best_hyp"]], g, o)
+    assert gated >= len(queries) - 2, gated
+
+
+def test_dubrovnik_batch_fixed_budget_equals_oracle(ctx):
+    """The throughput mode of the same batch (fixed budget, inlier-count selection) on a budget the
+    oracle replays in seconds: kept hypothesis and count equal the oracle's first maximum."""
+    queries = dubrovnik_queries()[:6]
+    budget, seed = 1500, 3000
+    got = ctx.ransac_batch(queries, SAMPLE_BASIC, seed=seed, budget=budget, select_mode=SELECT_INLIERS, early_exit=False)
+    for q, g in zip(queries, got):
+        ctx.set_query(*oracle_args(q))
+        s = ctx.sample(SAMPLE_BASIC, seed, q["query_id"], 0, budget)
+        s[:, 3] = np.where(s[:, 3] == 0xFFFFFFFF, 0, s[:, 3])
+        o = O.ransac(*oracle_args(q), s, select_coverage=False, early_exit=False, max_steps=budget)
+        assert (g["found"], g["steps"], g["best_hyp"], g["inliers"]) == (o["found"], budget, o["best_step"], o["hyposet"])
+        if g["best_sol"] == o["best_sol"]:
+            assert_pose_close(q, s[g["best_hyp"]], g, o)
+
+
+# ---- Project ---------------------------------------------------------------------------------------
+def test_project_batch_equals_oracle(ctx):
+    rng = np.random.default_rng(3)
+    for n in (1, 255, 256, 257, 5000):
+        q = synth.make_query(n, 0.4, 900 + n)
+        ctx.set_query(*oracle_args(q))
+        P = [O.compute_matrices(q["f_true"], q["C_true"], q["Rc_true"])] + [rng.normal(size=(3, 4)) for _ in range(4)]
+        P.append(np.zeros((3, 4)))                                   # 0/0: NaN on both sides
+        P = np.array(P)
+        p2, p3 = ctx.project_batch(P, want_3d=True)
+        assert p2.shape == (len(P), n, 2) and p3.shape == (n, 3)
+        for i in range(len(P)):
+            e2, e3 = O.project(P[i], q["X"], q["Y"], q["Z"])
+            assert np.array_equal(np.isnan(p2[i]), np.isnan(e2))
+            fin = ~np.isnan(e2)
+            # the same operations in the same order: equal to the last bit (bar: 1e-12 relative)
+            assert np.all(np.abs(p2[i][fin] - e2[fin]) <= 1e-12 * np.abs(e2[fin]))
+            assert np.array_equal(p2[i][fin], e2[fin])
+            assert np.array_equal(p3, e3)
+
+
+def test_process_fills_fitpoints_like_the_final_projection(ctx):
+    """basic.cpp:296-307: after the loop the fitted matches are reprojected with the kept pose."""
+    d = synth.make_query(1500, 0.3, 21)
+    q = Query(d["kx"], d["ky"], d["X"], d["Y"], d["Z"], d["width"], d["height"], 0.0)
+    qp = QueryProcessorBasic(ctx, seed=5)
+    assert qp.Process(q) is True
+    k = int(q.fitted_mask.sum())
+    assert k >= 12 and q.fitpoints_2d.shape == (k, 2) and q.fitpoints_3d.shape == (k, 3)
+    e2, e3 = O.project(q.proj_matrix(), d["X"], d["Y"], d["Z"])
+    assert np.array_equal(q.fitpoints_2d, e2[q.fitted_mask]) and np.array_equal(q.fitpoints_3d, e3[q.fitted_mask])
+    # every fitted match reprojects within the threshold of its keypoint
+    u = -(d["kx"][q.fitted_mask].astype(np.float64) - d["width"] / 2.0)
+    v = -(d["ky"][q.fitted_mask].astype(np.float64) - d["height"] / 2.0)
+    assert np.all(np.hypot(u - q.fitpoints_2d[:, 0], v - q.fitpoints_2d[:, 1]) < 0.5 + 1e-9)
+    # Project as a method of its own, on a subset
+    sub = np.arange(0, 1500, 7)
+    p2, p3 = QueryProcessor(ctx).Project(q, sub)
+    assert np.array_equal(p2, e2[sub]) and np.array_equal(p3, e3[sub])
+
+
+# ---- BASELINE configs[3]: advanced processor with its backmatching leg --------------------------------
+def advanced_case(n, n_in, seed, extra_frac):
+    """A query whose first 100 co-occurrence-sampled steps cannot reach 12 inliers (only n_in < 12
+    matches fit the planted pose) and a backmatching stub that appends 100 matches."""
+    d = synth.make_query(n, n_in / n, seed)
+    synth.add_camsets(d, seed + 1)
+    d2 = synth.append_matches(d, 100, extra_frac, seed + 2)
+    return d, d2
+
+
+def as_query(d):
+    return Query(d["kx"], d["ky"], d["X"], d["Y"], d["Z"], d["width"], d["height"], d["focal"], cam_off=d["cam_off"], cam_ids=d["cam_ids"])
+
+
+@pytest.mark.parametrize("n,n_in,seed,extra_frac,expect_leg", [(400, 8, 51, 0.9, 1), (300, 9, 61, 0.0, None), (500, 6, 71, 0.5, 1),
+                                                                  (300, 11, 124, 0.0, 0), (300, 11, 133, 0.0, 0)])
+def test_advanced_backmatching_leg_equals_oracle(ctx, n, n_in, seed, extra_frac, expect_leg):
+    """query_processor_advanced.cpp:583-606: after 100 steps without 12 inliers the matches are
+    extended, steps restart, and the old quality (a ratio against the OLD all-matches area) stays
+    the bar for the second 100 steps.  Both legs against the oracle on the exported tuples; the
+    caller's Query object receives the result."""
+    d, d2 = advanced_case(n, n_in, seed, extra_frac)
+    q = as_query(d)
+    calls = []
+
+    def backmatch(query):
+        calls.append(len(query.kx))
+        return as_query(d2)
+
+    qp = QueryProcessorAdvanced(ctx, seed=seed, backmatch=backmatch)
+    assert qp.Process(q, query_id=3) is True
+    assert calls == [n] and qp.backmatched and qp.steps == 200 and len(q.kx) == n + 100
+    s1, s2 = qp.samples[:100], qp.samples[100:]
+    for h in (0, 50, 99):
+        assert np.array_equal(s1[h], O.sample_advanced(seed, 3, h, 4, n, d["cam_off"], d["cam_ids"])[0])
+        assert np.array_equal(s2[h], O.sample_advanced(seed, 3, 100 + h, 4, n + 100, d2["cam_off"], d2["cam_ids"])[0])
+    o = O.ransac_backmatch(d, d2, s1, s2, select_coverage=True, max_steps=100)
+    assert o["second_leg"] and o["steps"] == 200
+    r = qp.result
+    assert r["found"] == o["found"]
+    if expect_leg is not None:
+        assert o["best_leg"] == expect_leg
+    assert qp.best_leg == o["best_leg"]
+    assert (r["best_hyp"], r["inliers"], r["area_fit"], r["area_all"]) == (o["best_step"], o["hyposet"], o["area_fit"], o["area_all"])
+    dd, ss = (d2, s2) if o["best_leg"] else (d, s1)
+    if r["best_sol"] == o["best_sol"]:
+        got = dict(focal=q.focal_length(), C=q.camera_position(), Rc=q.camera_rotation())
+        assert_pose_close(dd, ss[r["best_hyp"]], got, o)
+        # the caller's Query holds the kept pose, its projection matrix and the fitted matches
+        assert np.array_equal(q.camera_position(), r["C"]) and np.array_equal(q.camera_rotation(), r["Rc"])
+        diff = np.nonzero(q.fitted_mask[:len(o["mask"])] != o["mask"].astype(bool))[0]
+        assert len(diff) == 0 and not q.fitted_mask[len(o["mask"]):].any()
+    assert q.fitpoints_2d.shape == (int(q.fitted_mask.sum()), 2)
+
+
+def test_advanced_without_backmatching_when_first_leg_succeeds(ctx):
+    d = synth.add_camsets(synth.make_query(1200, 0.35, 31), 32)
+    d2 = synth.append_matches(d, 100, 0.5, 33)
+    q = as_query(d)
+    qp = QueryProcessorAdvanced(ctx, seed=6, backmatch=lambda query: as_query(d2))
+    assert qp.Process(q) is True and qp.steps == 100 and not qp.backmatched and len(q.kx) == 1200
+    o = O.ransac_backmatch(d, d2, qp.samples, None, select_coverage=True, max_steps=100)
+    assert not o["second_leg"] and o["hyposet"] >= 12
+    assert (qp.result["best_hyp"], qp.result["inliers"], qp.result["area_fit"]) == (o["best_step"], o["hyposet"], o["area_fit"])

@@ -13,13 +13,10 @@ from pose_estimation_amd import synth, SELECT_COVERAGE, SELECT_INLIERS, SAMPLE_B
 from pose_estimation_amd import P3p, P4pf, Query, QueryProcessorBasic, QueryProcessorAdvanced, PoseAmdError
 from test_oracle_golden import (P3P_FEATS, P3P_POINTS, P3P_GOLDEN, P4P_M, P4P_m, P4P_RGT, P4P_TGT, P4P_FGT, p3p_as_3x16)
 
+from gates import RTOL, relerr, p4pf_gate, p3p_gate, pose_tolerance
+
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
-RTOL = 1e-8
-
-
-def relerr(a, b, floor=1e-6):
-    return np.max(np.abs(a - b) / np.maximum(np.abs(b), floor))
 
 
 def upload(ctx, q):
@@ -74,18 +71,28 @@ def test_p3p_batch_random(ctx):
     f, P = synth.random_p3p_problems(3000, 42)
     st, Cc, Rc = ctx.p3p_batch(f, P)
     assert np.all(st == 0)
-    close = 0
+    # Bar: 1e-8 relative, or 20 x the reference algorithm's own rounding uncertainty on the problem
+    # (double oracle vs long-double oracle): the back-substitution has sqrt(1 - x^2) terms that
+    # amplify rounding near |x| = 1.  Problems on which the two oracles disagree about which of the
+    # four blocks are finite are ungated.
+    gated = agree = tight = 0
+    worst = 0.0
     for i in range(3000):
-        s0, C0, R0 = O.p3p(f[i], P[i])
-        assert s0 == 0
-        fin = np.isfinite(R0).all(axis=(1, 2)) & np.isfinite(C0).all(axis=1)
-        assert np.array_equal(fin, np.isfinite(Rc[i]).all(axis=(1, 2)) & np.isfinite(Cc[i]).all(axis=1))
-        if fin.any():
-            e = max(relerr(Cc[i][fin], C0[fin], 1e-3), relerr(Rc[i][fin], R0[fin], 1e-3))
-            close += e < 1e-6
-    # P3P back-substitution has sqrt(1 - x^2) terms that amplify rounding near |x| = 1; require
-    # the bulk to agree tightly and leave the tail to the scoring-level tests below
-    assert close >= 2950
+        g = p3p_gate(f[i], P[i])
+        if g is None:
+            continue
+        s1, C1, R1, fin, e_ref = g
+        assert s1 == 0
+        gated += 1
+        tight += e_ref < 1e-9
+        ok = np.array_equal(fin, np.isfinite(Rc[i]).all(axis=(1, 2)) & np.isfinite(Cc[i]).all(axis=1))
+        if ok and fin.any():
+            e = max(relerr(Cc[i][fin], C1[fin], 1e-3), relerr(Rc[i][fin], R1[fin], 1e-3))
+            ok = e < max(RTOL, 20 * e_ref)
+            worst = max(worst, e / max(RTOL, 20 * e_ref))
+        agree += ok
+    assert gated >= 2970 and tight >= 2400, (gated, tight)
+    assert agree >= gated - 3, f"{gated - agree} of {gated} gated problems beyond max(1e-8, 20 e_ref); worst ratio {worst:.2f}"
 
 
 def test_p4pf_reference_known_answer(ctx):
@@ -101,18 +108,6 @@ def test_p4pf_reference_known_answer(ctx):
     n0 = len(f)
     M = np.array([[0.0, 0, 1, 0], [0, 0, 0, 1], [0, 0, 0, 0]])
     assert P4pf(ctx).P4Pf_m(P4P_m, M, f, R, t) == -1 and len(f) == n0
-
-
-def p4pf_gate(m, M):
-    """Conditioning gate.  The reference algorithm (78x78 LU + eigenvectors) carries its own
-    rounding error: e_ref = |fp64 oracle - long-double oracle|.  Returns the long-double
-    solution and e_ref, or None when the two oracles disagree on the solution count."""
-    n, f, R, t = O.p4pf(m, M)
-    n2, f2, R2, t2 = O.p4pf(m, M, long_double=True)
-    if n != n2:
-        return None
-    e_ref = max(relerr(f, f2), relerr(R, R2, 1e-3), relerr(t, t2, 1e-3)) if n > 0 else 0.0
-    return n, f2, R2, t2, e_ref
 
 
 def p4pf_agrees(nsol, f, R, t, g):
@@ -171,7 +166,9 @@ def test_p4pf_lapack_fixture(ctx):
     for i, x in enumerate(g):
         ref = np.array(x["roots"]).reshape(-1, 4)
         v2 = np.mean(np.linalg.norm(m[i], axis=1))
-        ok += nsol[i] == len(ref) and (len(ref) == 0 or relerr(f[i, :len(ref)], ref[:, 0] * v2) < 1e-7)
+        # solution SETS are compared (sorted by focal length): the device orders solutions by
+        # ascending depth of the fourth point, LAPACK / Eigen by eigenvalue order
+        ok += nsol[i] == len(ref) and (len(ref) == 0 or relerr(np.sort(f[i, :len(ref)]), np.sort(ref[:, 0] * v2)) < 1e-7)
     assert ok >= len(g) - 1
 
 
@@ -333,6 +330,7 @@ def run_both(ctx, q, samples, select, early_exit, max_steps):
     upload(ctx, q)
     ctx.set_samples(samples)
     r = ctx.ransac_run(select, 0.5, early_exit, hyp_count=len(samples), want_per_hyp=True)
+    r["samples"] = samples
     o = O.ransac(q["kx"], q["ky"], q["X"], q["Y"], q["Z"], q["width"], q["height"], q["focal"], samples,
                  select_coverage=(select == SELECT_COVERAGE), early_exit=early_exit, max_steps=max_steps, want_mask=True)
     return r, o
@@ -352,10 +350,16 @@ def assert_same_outcome(ctx, q, r, o, select):
     mask = ctx.best_mask()
     assert mask.sum() == r["inliers"]
     if r["best_sol"] == o["best_sol"]:
-        assert relerr(r["C"], o["C"], 1e-3) < 1e-6 and relerr(r["Rc"], o["Rc"], 1e-3) < 1e-6
-        assert abs(r["focal"] - o["focal"]) <= 1e-6 * abs(o["focal"])
+        # the pose at the gated bar: 1e-8, or 20 x the reference algorithm's own rounding
+        # uncertainty on the kept sample; ungated (tol None) only if the oracle disagrees with
+        # its long-double self about the sample's solutions
+        tol = pose_tolerance(q, r["samples"][r["best_hyp"]])
+        if tol is not None:
+            assert relerr(r["C"], o["C"], 1e-3) < tol and relerr(r["Rc"], o["Rc"], 1e-3) < tol, tol
+            assert abs(r["focal"] - o["focal"]) <= tol * abs(o["focal"])
         P = O.compute_matrices(o["focal"], o["C"], o["Rc"])
         assert_masks_equal(q, P, mask, o["mask"])
+    return r["best_sol"] == o["best_sol"]
 
 
 @pytest.mark.parametrize("select", [SELECT_COVERAGE, SELECT_INLIERS])
