@@ -56,6 +56,19 @@ int pose_amd_quartic_batch(pose_amd_ctx *ctx, int count, const double *factors, 
 int pose_amd_p4pf_batch(pose_amd_ctx *ctx, int count, const double *m2d, const double *M3D, int *nsol, double *f,
                         double *R, double *t);
 
+/* No counterpart in the reference.  For callers that cannot allocate device memory (code under
+ * HIP graph capture, tight serving loops, harnesses that forbid hipMalloc): pose_amd_p4pf_batch
+ * on DEVICE-resident inputs and outputs, same kernels and bit-identical results, whose
+ * intermediate buffer (the reduced tail system of every problem, 604 bytes each) lives in a
+ * static device array of POSE_AMD_NOALLOC_MAX_COUNT entries (9.9 MB per GPU, held until the
+ * process ends) instead of a hipMalloc'ed one.  The call allocates nothing, is asynchronous on the
+ * context's stream (pose_amd_synchronize waits for it) and returns POSE_AMD_EINVAL for
+ * count > POSE_AMD_NOALLOC_MAX_COUNT.  All calls on one GPU share that array, whatever their
+ * context: calls that overlap on one GPU race; issue them on one stream or serialise them. */
+#define POSE_AMD_NOALLOC_MAX_COUNT 16384
+int pose_amd_p4pf_batch_noalloc(pose_amd_ctx *ctx, int count, const double *m2d_dev, const double *M3D_dev, int *nsol_dev,
+                                double *f_dev, double *R_dev, double *t_dev);
+
 /* ---- query data (the good_matches list of QueryProcessor*::Process) -------------------- */
 /* Uploads one query's correspondences (stands in for the SiftMatch / SIFT_keypoint /
  * point3D triple walk of query_processor.cpp:62-69).  lindex may be NULL (= 0..n-1).

@@ -52,6 +52,7 @@ SIGNATURES = {
     "pose_amd_p3p_batch": (C.c_int, [_ctx, C.c_int, _dp, _dp, _dp, _ip]),
     "pose_amd_quartic_batch": (C.c_int, [_ctx, C.c_int, _dp, _dp]),
     "pose_amd_p4pf_batch": (C.c_int, [_ctx, C.c_int, _dp, _dp, _ip, _dp, _dp, _dp]),
+    "pose_amd_p4pf_batch_noalloc": (C.c_int, [_ctx, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "pose_amd_set_query": (C.c_int, [_ctx, C.c_int, _fp, _fp, _fp, _fp, _fp, _up, C.c_int, C.c_int, C.c_double]),
     "pose_amd_set_camsets": (C.c_int, [_ctx, _up, _up]),
     "pose_amd_compute_matrices_batch": (C.c_int, [_ctx, C.c_int, _dp, _dp, _dp, _dp]),

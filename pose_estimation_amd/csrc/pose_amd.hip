@@ -15,8 +15,21 @@
 
 using namespace pose_amd;
 
+// Scratch of the allocation-free entry point pose_amd_p4pf_batch_noalloc: the reduced 5 x 15
+// tail systems the elimination kernel hands to the finish kernel ([75][count] doubles) followed
+// by one status word per problem.  One copy per GPU, held until the process ends.  In host code
+// the array's name is only a handle for hipGetSymbolAddress; the device address of each GPU's
+// copy is resolved once per device in pose_amd_create and kept in g_noalloc_scratch.
+#define NOALLOC_MAX_COUNT POSE_AMD_NOALLOC_MAX_COUNT
+constexpr size_t NOALLOC_STATUS_OFFSET = (size_t)NOALLOC_MAX_COUNT * P4PF_TAIL * sizeof(double);
+constexpr size_t NOALLOC_SCRATCH_BYTES = NOALLOC_STATUS_OFFSET + (size_t)NOALLOC_MAX_COUNT * sizeof(int);
+static __device__ __align__(256) unsigned char scratch[NOALLOC_SCRATCH_BYTES];
+
 namespace {
 std::string g_create_error;
+constexpr int MAX_DEVICES = 64;
+std::mutex g_noalloc_lock;
+void *g_noalloc_scratch[MAX_DEVICES] = {nullptr};   // device address of `scratch` on each GPU
 
 struct dev_buf {
     void *p = nullptr;
@@ -210,6 +223,16 @@ int pose_amd_create(int device, pose_amd_ctx **out)
         return POSE_AMD_EHIP;
     };
     if ((e = hipSetDevice(device)) != hipSuccess) return bail("hipSetDevice", e);
+    if (device < MAX_DEVICES) {
+        // each GPU holds its own copy of the scratch array at its own address: resolve it once
+        // per device, with that device current
+        std::lock_guard<std::mutex> g(g_noalloc_lock);
+        if (!g_noalloc_scratch[device]) {
+            void *ptr = nullptr;
+            if ((e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch))) != hipSuccess) return bail("hipGetSymbolAddress(scratch)", e);
+            g_noalloc_scratch[device] = ptr;
+        }
+    }
     hipDeviceProp_t prop;
     if ((e = hipGetDeviceProperties(&prop, device)) != hipSuccess) return bail("hipGetDeviceProperties", e);
     snprintf(c->dev_name, sizeof c->dev_name, "%s (%s)", prop.name, prop.gcnArchName);
@@ -332,6 +355,40 @@ int pose_amd_p4pf_batch(pose_amd_ctx *ctx, int count, const double *m2d, const d
     if ((rc = download(ctx, R, ctx->out2.p, (size_t)count * 720))) return rc;
     if ((rc = download(ctx, t, ctx->out3.p, (size_t)count * 240))) return rc;
     return pose_amd_synchronize(ctx);
+}
+
+// The same kernels as pose_amd_p4pf_batch on device-resident inputs and outputs, with the
+// intermediate tail systems in the per-device static scratch array: no hipMalloc / hipFree /
+// allocating call on this path.  Asynchronous on the context's stream.
+int pose_amd_p4pf_batch_noalloc(pose_amd_ctx *ctx, int count, const double *m2d_dev, const double *M3D_dev, int *nsol_dev,
+                                double *f_dev, double *R_dev, double *t_dev)
+{
+    if (!ctx || count < 0 || (count && (!m2d_dev || !M3D_dev || !nsol_dev || !f_dev || !R_dev || !t_dev)))
+        return fail(ctx, POSE_AMD_EINVAL, "p4pf_batch_noalloc: bad argument");
+    if (count > NOALLOC_MAX_COUNT)
+        return fail(ctx, POSE_AMD_EINVAL, "p4pf_batch_noalloc: count exceeds POSE_AMD_NOALLOC_MAX_COUNT (16384); split the batch or use pose_amd_p4pf_batch");
+    if (count == 0) return POSE_AMD_OK;
+    void *sp = ctx->device < MAX_DEVICES ? g_noalloc_scratch[ctx->device] : nullptr;
+    if (!sp) return fail(ctx, POSE_AMD_ESTATE, "p4pf_batch_noalloc: scratch address of this device was not resolved");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    double *arows = (double *)sp;                                    // [75][count], fully rewritten for every live problem
+    int *pstatus = (int *)((char *)sp + NOALLOC_STATUS_OFFSET);      // [count], written for every problem by the elimination
+    // unused solution slots read as zero, like pose_amd_p4pf_batch's outputs
+    HIPCHK(ctx, hipMemsetAsync(f_dev, 0, (size_t)count * 80, ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(R_dev, 0, (size_t)count * 720, ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(t_dev, 0, (size_t)count * 240, ctx->stream));
+    const query_dev q = make_query(ctx);                             // not read: the problems come from m2d / M3D
+    const int slots = (ctx->cus ? ctx->cus : 256) * 8;
+    int batch = 4 * cdiv(cdiv(count, slots), 4);
+    batch = std::max(4, std::min(batch, ELIM_BATCH));
+    hipLaunchKernelGGL(k_p4pf_elim, dim3(cdiv(count, batch)), dim3(64), 0, ctx->stream, q, (uint32_t)count, (const uint32_t *)nullptr, m2d_dev, M3D_dev,
+                       arows, pstatus, batch);
+    HIPCHK(ctx, hipGetLastError());
+    hipLaunchKernelGGL(k_p4pf_finish, dim3(cdiv(count, 64)), dim3(64), 0, ctx->stream, q, (uint32_t)count, (const uint32_t *)nullptr, m2d_dev, M3D_dev,
+                       (const double *)arows, (const int *)pstatus, (double *)nullptr, (double *)nullptr, nsol_dev, f_dev, R_dev, t_dev,
+                       (float *)nullptr, 0.0);
+    HIPCHK(ctx, hipGetLastError());
+    return POSE_AMD_OK;
 }
 
 // ---- query data -----------------------------------------------------------------------------
