@@ -8,8 +8,9 @@ HDRS := $(wildcard $(CSRC)/*.h) include/pose_amd.h
 SHIM := tests/host_shim/libhost_eig.so
 
 FACADE_TEST := tests/cpp/facade_test
+IO_TEST := tests/cpp/io_test
 
-all: $(LIB) oracle $(SHIM) $(FACADE_TEST)
+all: $(LIB) oracle $(SHIM) $(FACADE_TEST) $(IO_TEST)
 
 $(LIB): $(CSRC)/pose_amd.hip $(HDRS)
 	$(HIPCC) -O3 -std=c++17 --offload-arch=$(ARCH) -fPIC -shared -pthread -Wall -Wno-unused-function -o $@ $<
@@ -18,15 +19,20 @@ $(LIB): $(CSRC)/pose_amd.hip $(HDRS)
 $(SHIM): tests/host_shim/eig_shim.hip $(HDRS)
 	$(HIPCC) -O2 -std=c++17 --offload-arch=$(ARCH) -fPIC -shared -Wno-unused-function -o $@ $<
 
-# Test driver of the C++ host facade (plain g++, links the library through its C ABI).
-$(FACADE_TEST): tests/cpp/facade_test.cpp include/pose_amd.hpp include/pose_amd.h $(LIB)
+# Test drivers of the C++ host facade (plain g++, link the library through its C ABI; the GPU
+# one also links the CPU oracle, as its checker).
+$(FACADE_TEST): tests/cpp/facade_test.cpp include/pose_amd.hpp include/pose_amd_io.hpp include/pose_amd.h $(LIB) oracle
+	g++ -std=c++17 -O1 -Wall -Iinclude $< -o $@ -Lpose_estimation_amd -lpose_amd -Loracle/build -loracle \
+	    -Wl,-rpath,'$$ORIGIN/../../pose_estimation_amd' -Wl,-rpath,'$$ORIGIN/../../oracle/build'
+
+$(IO_TEST): tests/cpp/io_test.cpp include/pose_amd.hpp include/pose_amd_io.hpp include/pose_amd.h $(LIB)
 	g++ -std=c++17 -O1 -Wall -Iinclude $< -o $@ -Lpose_estimation_amd -lpose_amd -Wl,-rpath,'$$ORIGIN/../../pose_estimation_amd'
 
 oracle:
 	$(MAKE) -C oracle
 
 clean:
-	rm -f $(LIB) $(SHIM) $(FACADE_TEST)
+	rm -f $(LIB) $(SHIM) $(FACADE_TEST) $(IO_TEST)
 	$(MAKE) -C oracle clean
 
 .PHONY: all oracle clean

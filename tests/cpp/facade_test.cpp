@@ -7,6 +7,8 @@
 #include <random>
 
 #include "pose_amd.hpp"
+#include "pose_amd_io.hpp"
+#include "../../oracle/pose_oracle.h"      // the CPU oracle: the checker of this test, nothing more
 
 using namespace pose_estimation_amd;
 
@@ -183,6 +185,149 @@ static void test_batch()
     }
 }
 
+// SoA view of a scene's matches for the oracle
+struct OracleQuery {
+    std::vector<float> kx, ky, X, Y, Z;
+    orc_query q;
+    OracleQuery(Scene &s, size_t n)
+    {
+        for (size_t i = 0; i < n; ++i) {
+            const SiftMatch &m = s.matches[i];
+            kx.push_back(s.query.sift_keypoints()[m.lindex].x); ky.push_back(s.query.sift_keypoints()[m.lindex].y);
+            X.push_back(s.sifts[m.mindex].point.x); Y.push_back(s.sifts[m.mindex].point.y); Z.push_back(s.sifts[m.mindex].point.z);
+        }
+        q.n = (int)n; q.kx = kx.data(); q.ky = ky.data(); q.X = X.data(); q.Y = Y.data(); q.Z = Z.data();
+        q.width = s.query.image_width(); q.height = s.query.image_height(); q.focal = 0.0;
+    }
+};
+
+// QueryProcessor::Project and the fitpoints Process leaves in the query (query_processor.cpp:46-86,
+// basic.cpp:296-307) against the oracle's projection: same operations, same order, equal bits.
+static void test_project()
+{
+    Scene s = make_scene(700, 280, false, 31u);
+    QueryProcessorBasic basic;
+    basic.seed = 11;
+    CHECK(basic.Process(s.query, s.matches, s.sifts));
+    CHECK(s.query.fitpoints_2d().size() == basic.fitted_matches.size() && s.query.fitpoints_3d().size() == basic.fitted_matches.size());
+    OracleQuery oq(s, s.matches.size());
+    const Mat<3, 4> Pm = s.query.proj_matrix();
+    double P[12];
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 4; ++c) P[4 * r + c] = Pm(r, c);
+    std::vector<double> e2(2 * s.matches.size()), e3(3 * s.matches.size());
+    orc_project(P, oq.q.n, oq.q.X, oq.q.Y, oq.q.Z, e2.data(), e3.data());
+    std::vector<Vector2d> p2;
+    std::vector<Vector3d> p3;
+    CHECK(basic.Project(s.query, p2, p3, s.matches, s.query.sift_keypoints(), s.sifts));
+    CHECK(p2.size() == s.matches.size());
+    bool same = true;
+    for (size_t i = 0; i < s.matches.size(); ++i)
+        same = same && p2[i](0, 0) == e2[2 * i] && p2[i](1, 0) == e2[2 * i + 1] && p3[i](0, 0) == e3[3 * i] && p3[i](2, 0) == e3[3 * i + 2];
+    CHECK(same);
+    // the stored fitpoints are the projections of the fitted matches, in match order
+    size_t k = 0;
+    bool fit_ok = true;
+    for (size_t i = 0; i < s.matches.size() && k < basic.fitted_matches.size(); ++i)
+        if (s.matches[i].lindex == basic.fitted_matches[k].lindex) {
+            fit_ok = fit_ok && s.query.fitpoints_2d()[k](0, 0) == e2[2 * i] && s.query.fitpoints_3d()[k](1, 0) == e3[3 * i + 1];
+            ++k;
+        }
+    CHECK(fit_ok && k == basic.fitted_matches.size());
+}
+
+// The advanced processor's backmatching leg (advanced.cpp:583-606) against the oracle: 100 steps
+// that cannot reach 12 inliers, a stand-in Backmatching that appends 100 matches, 100 more steps
+// with the first leg's quality as the bar.
+struct BackmatchStub { Scene *scene; Scene *extra; };
+static bool append_extra(std::vector<SiftMatch> &good_matches, void *user)
+{
+    BackmatchStub *b = (BackmatchStub *)user;
+    const unsigned kbase = (unsigned)b->scene->query.sift_keypoints().size(), pbase = (unsigned)b->scene->sifts.size();
+    for (size_t i = 0; i < 100; ++i) {
+        b->scene->query.sift_keypoints().push_back(b->extra->query.sift_keypoints()[i]);
+        b->scene->sifts.push_back(b->extra->sifts[i]);
+        SiftMatch m = b->extra->matches[i];
+        m.lindex = kbase + (unsigned)i; m.mindex = pbase + (unsigned)i;
+        good_matches.push_back(m);
+    }
+    return true;
+}
+
+static void test_backmatching()
+{
+    for (int variant = 0; variant < 2; ++variant) {
+        Scene s = make_scene(400, 9, false, 41u + variant);          // 9 inliers: the first leg stays below 12
+        Scene extra = make_scene(100, variant == 0 ? 90 : 0, false, 43u + variant);   // same planted camera; all-outlier variant
+        s.matches[0].camset = {1, 2, 3, 4, 5, 6};                    // somebody must be seen by >= 5 cameras
+        BackmatchStub stub{&s, &extra};
+        QueryProcessorAdvanced adv;
+        adv.seed = 47; adv.query_id = 2;
+        adv.backmatching = append_extra; adv.backmatching_user = &stub;
+        CHECK(adv.Process(s.query, s.matches, s.sifts));
+        CHECK(adv.backmatched && adv.result.steps == 200 && adv.samples.size() == 800 && s.matches.size() == 500);
+        OracleQuery q1(s, 400), q2(s, 500);
+        orc_ransac_params prm = {1, 0.5, 100, 10, 12, 0};
+        orc_ransac_result o;
+        std::vector<uint8_t> mask(500);
+        int leg = -1;
+        const int second = orc_ransac_backmatch(&q1.q, &q2.q, &prm, adv.samples.data(), 100, adv.samples.data() + 400, 100, &o, mask.data(), &leg);
+        CHECK(second == 1 && o.steps == 200);
+        CHECK(adv.best_leg == leg && adv.result.found == o.found);
+        CHECK(adv.result.best_hyp == o.best_step && adv.result.inliers == o.hyposet && adv.result.area_fit == o.area_fit &&
+              adv.result.area_all == o.area_all);
+        if (variant == 0) CHECK(leg == 1 && o.hyposet >= 50);
+        CHECK(adv.fitted_matches.size() == o.hyposet && s.query.fitpoints_2d().size() == o.hyposet);
+        if (adv.result.best_sol == o.best_sol) {
+            const Vector3d C = s.query.camera_position();
+            double d = 0, nrm = 0;
+            for (int k = 0; k < 3; ++k) { d += (C(k, 0) - o.C[k]) * (C(k, 0) - o.C[k]); nrm += o.C[k] * o.C[k]; }
+            CHECK(std::sqrt(d) <= 1e-6 * std::sqrt(nrm) + 1e-9);     // loose here: the gated 1e-8 comparison is in the Python suite
+        }
+    }
+}
+
+// benchmark.cpp:19-67 through the C++ Benchmark: golden poses are the planted ones
+static void test_benchmark()
+{
+    QuerySource src;
+    std::vector<Query> golden;
+    for (int i = 0; i < 3; ++i) {
+        Scene s = make_scene(500, 200, i == 1, 70u + i);
+        const unsigned base = (unsigned)src.sifts.size();
+        src.sifts.insert(src.sifts.end(), s.sifts.begin(), s.sifts.end());
+        for (SiftMatch &m : s.matches) m.mindex += base;
+        src.queries.push_back(s.query);
+        src.good_matches.push_back(s.matches);
+        bundler_camera cam;                                       // Bundler convention: looks down -Z
+        cam.focal_length = 1200.0; cam.width = 1600; cam.height = 1200;
+        cam.rotation(0, 0) = -1.0; cam.rotation(1, 1) = 1.0; cam.rotation(2, 2) = -1.0;      // diag(-1,1,-1) * I
+        const double C[3] = {3.0, -2.0, 1.0};
+        for (int r = 0; r < 3; ++r) cam.translation(r, 0) = -cam.rotation(r, r) * C[r];   // t = -R C
+        golden.push_back(GoldenQueryFromCamera(cam));
+        CHECK(std::fabs(golden.back().camera_position()(0, 0) - 3.0) < 1e-12 && golden.back().camera_rotation()(0, 0) == 1.0 &&
+              golden.back().camera_rotation()(2, 2) == 1.0);
+    }
+    QueryProcessorBasic basic;
+    basic.seed = 5;
+    const std::string path = "/tmp/pose_amd_benchmark_test.txt";
+    std::vector<BenchmarkRow> rows = Benchmark(src, golden, &basic, path, nullptr);
+    CHECK(rows.size() == 3);
+    std::ifstream in(path);
+    std::string line;
+    int nlines = 0;
+    while (std::getline(in, line)) {
+        int idx = 0;
+        double sec = 0, pe = 0, re = 0, fe = 0;
+        CHECK(std::sscanf(line.c_str(), "%d,%lf,%lf,%lf,%lf", &idx, &sec, &pe, &re, &fe) == 5);
+        CHECK(idx == nlines + 1 && sec > 0 && pe < 3.0 && re < 0.1 && std::fabs(fe) < 60.0);
+        CHECK(std::fabs(pe - rows[(size_t)nlines].position_error) <= 1e-11 * std::max(1.0, pe));
+        ++nlines;
+    }
+    CHECK(nlines == 3);
+    CHECK(src.queries[0].camera_position()(0, 0) == 0.0);           // Benchmark works on copies, like GetQuery(i, false)
+}
+
 int main()
 {
     try {
@@ -190,6 +335,9 @@ int main()
         test_p4pf();
         test_processors();
         test_batch();
+        test_project();
+        test_backmatching();
+        test_benchmark();
     } catch (const std::exception &e) {
         std::printf("EXCEPTION %s\n", e.what());
         return 2;

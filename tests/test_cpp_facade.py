@@ -23,6 +23,15 @@ def test_facade_refuses_to_run_without_gpu():
     assert r.returncode == 2 and b"pose_amd_create" in r.stdout
 
 
+def test_io_readers_and_golden_pose_convention(tmp_path):
+    """Lowe .key reader, bundle.out reader and LoadGoldenQuery of include/pose_amd_io.hpp (host only)."""
+    exe = os.path.join(ROOT, "tests", "cpp", "io_test")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", ROOT, "tests/cpp/io_test"])
+    r = subprocess.run([exe, str(tmp_path)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=60)
+    assert r.returncode == 0 and b"io ok" in r.stdout, r.stdout.decode()
+
+
 @pytest.mark.gpu
 def test_facade_on_gpu():
     r = subprocess.run([_exe()], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)

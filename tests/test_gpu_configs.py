@@ -208,3 +208,33 @@ def test_advanced_without_backmatching_when_first_leg_succeeds(ctx):
     o = O.ransac_backmatch(d, d2, qp.samples, None, select_coverage=True, max_steps=100)
     assert not o["second_leg"] and o["hyposet"] >= 12
     assert (qp.result["best_hyp"], qp.result["inliers"], qp.result["area_fit"]) == (o["best_step"], o["hyposet"], o["area_fit"])
+
+
+# ---- the eigen step on the benchmark's own sample stream ----------------------------------------------
+def test_eigen_step_root_sets_on_benchmark_stream(ctx, record_property):
+    """The device replaces the complex Schur eigen-solver of P4pf.cpp:1123-1223 by a real-root
+    finder on the deflated sextic.  How often does that change the number of accepted roots on the
+    sample stream of the headline benchmark (4 000 matches, 10 % inliers: nine tuples in ten
+    contain an outlier)?  Counted against the double oracle, the long-double oracle and, as the
+    fair figure, on the tuples where those two agree with each other."""
+    from gates import sample_problem
+    q = synth.make_query(4000, 0.10, 2)
+    ctx.set_query(*oracle_args(q))
+    H = 6000
+    samples = ctx.sample(SAMPLE_BASIC, 1002, 0, 0, H)
+    r = ctx.ransac_run(SELECT_INLIERS, 0.5, early_exit=False, hyp_count=H, want_per_hyp=True)
+    dev = np.maximum(r["nsol"], 0)
+    n_d = np.zeros(H, int); n_ld = np.zeros(H, int)
+    for h in range(H):
+        m2d, M3D = sample_problem(q, samples[h])
+        n_d[h] = max(O.p4pf(m2d, M3D)[0], 0)
+        n_ld[h] = max(O.p4pf(m2d, M3D, long_double=True)[0], 0)
+    stable = n_d == n_ld
+    rates = dict(vs_double=float(np.mean(dev != n_d)), vs_long_double=float(np.mean(dev != n_ld)),
+                 oracle_vs_its_long_double_self=float(np.mean(~stable)), on_stable_tuples=float(np.mean(dev[stable] != n_d[stable])),
+                 device_fewer_on_stable=float(np.mean(dev[stable] < n_d[stable])), mean_roots=float(dev.mean()))
+    print("root-set mismatch rates on the benchmark stream:", rates)
+    for k, v in rates.items():
+        record_property(k, v)
+    assert stable.mean() > 0.97
+    assert rates["on_stable_tuples"] < 0.01, rates

@@ -116,6 +116,88 @@ def test_p4pf_matches_lapack_restatement():
     assert checked >= 100
 
 
+def test_p4pf_matches_independent_numpy_restatement():
+    """The whole of P4Pf_m once more in NumPy (tests/np_ref.py): template coefficients derived from
+    the geometric constraints instead of transcribed, LAPACK solve / eig, scale fix and rigid fit
+    with np.linalg.svd (P4pf.cpp:395-507, 101-235).  The oracle's coefficients must equal the
+    derived ones, and its solutions (f, R, t) the NumPy ones at the gated bar."""
+    from gates import p4pf_gate, relerr
+    m, M = synth.random_p4pf_problems(300, 78)
+    total = ok = 0
+    for i in range(300):
+        n, k, A, roots = O.p4pf_stages(m[i], M[i])
+        if n < 0:
+            assert np_ref.p4pf_numpy(m[i], M[i])[0] == -1
+            continue
+        mm, MM = m[i].T.copy(), M[i].T.copy()
+        MM -= (MM.sum(axis=1) / 4)[:, None]
+        MM /= np.sqrt((MM * MM).sum(axis=0)).sum() / 4
+        mm /= np.sqrt((mm * mm).sum(axis=0)).sum() / 4
+        d2 = lambda a, b: ((MM[:, a] - MM[:, b]) ** 2).sum()   # noqa: E731
+        kg = np_ref.coefs_from_geometry(mm.T, (d2(0, 1), d2(0, 2), d2(0, 3), d2(1, 2), d2(1, 3), d2(2, 3)))
+        assert np.max(np.abs(kg - k) / np.maximum(1.0, np.abs(k))) < 1e-12
+        g = p4pf_gate(m[i], M[i])
+        if g is None:
+            continue
+        n1, f1, R1, t1, e_ref = g
+        n2, f2, R2, t2 = np_ref.p4pf_numpy(m[i], M[i])
+        total += 1
+        if n1 != n2:
+            continue
+        ok += n1 <= 0 or max(relerr(f2, f1), relerr(R2, R1, 1e-3), relerr(t2, t1, 1e-3)) < max(1e-8, 20 * e_ref)
+    assert total >= 290 and ok >= total - 4, (ok, total)
+
+
+def test_project_matches_numpy():
+    """query_processor.cpp:46-86 against a plain NumPy product."""
+    q = synth.make_query(300, 0.5, 5)
+    P = O.compute_matrices(q["f_true"], q["C_true"], q["Rc_true"])
+    p2, p3 = O.project(P, q["X"], q["Y"], q["Z"])
+    Xh = np.stack([q["X"], q["Y"], q["Z"], np.ones(300, np.float32)], 1).astype(np.float64)
+    pr = Xh @ P.T
+    assert np.allclose(p2, pr[:, :2] / pr[:, 2:3], rtol=1e-13, atol=0) and np.array_equal(p3, Xh[:, :3])
+
+
+def test_backmatching_leg_carries_quality_and_restarts_steps():
+    """orc_ransac_backmatch (query_processor_advanced.cpp:583-606): the second leg runs only when the
+    first ends below min(n / 10, 12) inliers, its steps restart, and a pose of the second leg must
+    beat the first leg's quality ratio although the all-matches area changed."""
+    d = synth.add_camsets(synth.make_query(300, 11 / 300, 124), 125)
+    d2 = synth.append_matches(d, 100, 0.0, 126)
+    s1 = np.array([O.sample_advanced(124, 3, h, 4, 300, d["cam_off"], d["cam_ids"])[0] for h in range(100)], np.uint32)
+    s2 = np.array([O.sample_advanced(124, 3, 100 + h, 4, 400, d2["cam_off"], d2["cam_ids"])[0] for h in range(100)], np.uint32)
+    args = lambda q: (q["kx"], q["ky"], q["X"], q["Y"], q["Z"], q["width"], q["height"], q["focal"])   # noqa: E731
+    first = O.ransac(*args(d), s1, select_coverage=True, early_exit=False, max_steps=100)
+    both = O.ransac_backmatch(d, d2, s1, s2, select_coverage=True, max_steps=100)
+    assert first["hyposet"] < 12 and both["second_leg"] and both["steps"] == 200
+    alone = O.ransac(*args(d2), s2, select_coverage=True, early_exit=False, max_steps=100)
+    q1 = np.float32(first["area_fit"]) / np.float32(first["area_all"])
+    q2 = np.float32(alone["area_fit"]) / np.float32(alone["area_all"]) if alone["found"] else np.float32(0)
+    assert both["best_leg"] == int(q2 > q1)                       # the best of leg 2 wins only with a higher ratio
+    kept = alone if q2 > q1 else first
+    assert (both["best_step"], both["hyposet"], both["area_fit"], both["area_all"]) == (kept["best_step"], kept["hyposet"], kept["area_fit"], kept["area_all"])
+    # no second leg when the first one reached the threshold, or when no backmatcher exists
+    good = synth.add_camsets(synth.make_query(600, 0.4, 9), 10)
+    sg = np.array([O.sample_advanced(1, 0, h, 4, 600, good["cam_off"], good["cam_ids"])[0] for h in range(100)], np.uint32)
+    r = O.ransac_backmatch(good, synth.append_matches(good, 100, 0.5, 11), sg, sg, select_coverage=True, max_steps=100)
+    assert not r["second_leg"] and r["steps"] == 100 and r["hyposet"] >= 12
+    assert not O.ransac_backmatch(d, None, s1, None, select_coverage=True, max_steps=100)["second_leg"]
+
+
+def test_p3p_long_double_oracle_is_the_same_algorithm():
+    """The long-double P3P (the conditioning gate of the GPU tests) agrees with the double one to
+    rounding on well-conditioned problems and passes the reference's own golden vector."""
+    sol = O.p3p(P3P_FEATS.T, P3P_POINTS.T, long_double=True)
+    assert sol[0] == 0 and np.linalg.norm(p3p_as_3x16(sol[1], sol[2]) - P3P_GOLDEN) < 0.15
+    f, P = synth.random_p3p_problems(300, 3)
+    close = 0
+    for i in range(300):
+        a, b = O.p3p(f[i], P[i]), O.p3p(f[i], P[i], long_double=True)
+        fin = np.isfinite(a[2]).all(axis=(1, 2)) & np.isfinite(b[2]).all(axis=(1, 2))
+        close += fin.any() and np.max(np.abs(a[2][fin] - b[2][fin])) < 1e-8
+    assert close >= 280
+
+
 def test_p4pf_degenerate_returns_minus_one():
     M = np.array([[0.0, 0, 0], [0.0, 0, 0], [1.0, 0, 0], [0.0, 1, 0]])      # two identical world points
     m = np.array([[0.1, 0.2], [0.3, -0.1], [-0.2, 0.4], [0.5, 0.5]])

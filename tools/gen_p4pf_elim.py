@@ -36,6 +36,7 @@ RHS = list(range(78, 88))
 QUAD_BCAST = os.environ.get("P4PF_ELIM_QUAD_BCAST", "lds")   # pivot-row broadcast: "lds" (write + broadcast read) or "bpermute"
 SKIP = os.environ.get("P4PF_ELIM_SKIP", "")    # timing experiments only: "stage1" or "stage2" leaves that stage out
 PREFETCH = int(os.environ.get("P4PF_ELIM_PREFETCH", "0"))     # stage-1 steps between an LDS read and its first use (0..8 measured the same)
+FAKE_BLOCK = int(os.environ.get("P4PF_ELIM_FAKE_BLOCK", "0"))   # timing experiment only (wrong results): publish the pivot row every n-th step only
 QUAD_CHUNK = int(os.environ.get("P4PF_ELIM_QUAD_CHUNK", "16"))   # pivot-row entries in flight per group of broadcasts
 
 
@@ -396,7 +397,8 @@ def emit(sched):
                 a_, b_ = pr[0], pr[-1]
                 w(f"        const v2f64 s{a_} = {{sl ? r{a_}_1 : r{a_}_0, sl ? r{b_}_1 : r{b_}_0}};")
             w("        const unsigned long long wm = __builtin_amdgcn_ballot_w64(lane == L);")
-            masked_writes("wm", lambda pr: f"s{pr[0]}")
+            if not (FAKE_BLOCK and (si - 2) % FAKE_BLOCK != FAKE_BLOCK - 1):
+                masked_writes("wm", lambda pr: f"s{pr[0]}")
             w("        __builtin_amdgcn_wave_barrier();")
             for i0 in range(0, len(pairs), QUAD_CHUNK // 2):
                 chunk = pairs[i0:i0 + QUAD_CHUNK // 2]
