@@ -1,20 +1,30 @@
 #!/usr/bin/env python3
 """Benchmark of the RANSAC pose-hypothesis hot path on MI355X.
 
-Workload (BASELINE.json configs[1]): one synthetic query with 4 000 2D-3D matches, 10 %
-inliers, unknown focal (P4Pf), 1 M hypotheses per step.  One step = sample 1 M minimal
-4-tuples on the device, solve P4Pf for each, score every returned pose against all 4 000
-correspondences, select the best pose.  Inputs are resident in HBM before the timed region.
+Default workload (BASELINE.json configs[1]): one synthetic query with 4 000 2D-3D matches, 10 %
+inliers, unknown focal (P4Pf), 1 M hypotheses per step.  One step = sample 1 M minimal 4-tuples
+on the device, solve P4Pf for each, score every returned pose against all 4 000 correspondences,
+select the best pose.  Inputs are resident in HBM before the timed region.
 
-N > 1 GPUs (launched by torch.distributed.run, one rank per GPU): the hypothesis range is
-sharded, every rank evaluates its own 1 M hypotheses of the same query per step (weak
-scaling) and the packed (inlier count, ~hypothesis id) keys are max-all-reduced over RCCL.
+Other workloads (one JSON line each, same fields): --known-focal / --matches / --inlier-frac
+reshape the single-query run (configs[0] and configs[4] shapes); --workload dubrovnik runs the
+800-query batch of configs[2] (fixed budget, or --early-exit for the reference's loop) and
+configs[3] (--advanced).
+
+N > 1 GPUs: one rank per GPU.  Launched by torch.distributed.run the ranks find RANK / WORLD_SIZE
+in the environment; started plainly as `python bench.py --gpus N`, this script starts the N
+ranks itself as child processes (before anything touches the GPU) and relays rank 0's line.
+The single-query workload shards the hypothesis range (every rank evaluates its own 1 M
+hypotheses of the same query per step, weak scaling) and max-all-reduces the packed
+(inlier count, ~hypothesis id) keys over RCCL; the batch workload partitions the queries.
 
 Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -25,19 +35,21 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 FP64_VECTOR_PEAK_TFLOPS = 78.6     # MI355X fp64 vector peak: 256 CU x 4 SIMD x 16 FMA lanes/clk x 2 x 2.4 GHz
+BF16_MFMA_PEAK_TFLOPS = 2500.0     # dense bf16 matrix peak
 HBM_PEAK_GBS = 8000.0
 # Algorithmic fp64 work per unit of each kernel:
 SCORE_FLOP_PER_PAIR = 27           # reference formula per (pose, correspondence): 3x4 product, 2 div, distance, compare
 ELIM_FLOP_PER_HYP = 2.28e4         # sparsity-exploiting elimination of the 78x88 template down to the 5x15 tail (22 285) + coefficient formulas
 P3P_FLOP_PER_HYP = 5.0e2           # Kneip P3P + Ferrari quartic per sample
-FINISH_FLOP_PER_HYP = 2.3e4        # executed fp64 lane-operations per hypothesis, from SQ_INSTS_VALU_*_F64 (profiles/r1_traffic.json)
+FINISH_FLOP_PER_HYP = 2.3e4        # executed fp64 lane-operations per hypothesis of the eigen step / pose recovery (counters; no closed-form count)
+SCREEN_MFMA_FLOP_PER_PAIR = 96     # what the matrix-core screen executes: three v_mfma_f32_32x32x16_bf16 per 32 x 32 pairs
 
 
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--hyps", type=int, default=1 << 20, help="hypotheses per GPU per step")
     ap.add_argument("--matches", type=int, default=4000)
     ap.add_argument("--inlier-frac", type=float, default=0.10)
@@ -55,10 +67,28 @@ def main():
                     help="dubrovnik: configs[3], the advanced processor (co-occurrence sampling over camera sets, 100 steps, no early exit)")
     ap.add_argument("--python-threads", action="store_true", help="dubrovnik: drive the contexts from Python threads instead of pose_amd_ransac_batch")
     ap.add_argument("--host-threads", type=int, default=16, help="dubrovnik: contexts (streams) per GPU driven concurrently")
-    args = ap.parse_args()
-    if args.workload == "dubrovnik":
-        return bench_dubrovnik(args)
+    return ap.parse_args()
 
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as children through
+    torch.distributed.run (nothing in this process has touched the GPU), relay rank 0's JSON line,
+    return the children's exit code."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % args.gpus, "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, env=env)
+    lines = [l for l in p.stdout.decode(errors="replace").splitlines() if l.startswith("{")]
+    if lines:
+        print(lines[-1])
+    return p.returncode
+
+
+def setup_ranks(args):
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -74,9 +104,31 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
         else:
             dist.init_process_group("gloo")
-    elif args.gpus > 1:
-        print("bench.py: --gpus > 1 must be launched through torch.distributed.run", file=sys.stderr)
-        return 2
+    return rank, world, dev_index, red_dev, torch, dist
+
+
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def host_cores():
+    return min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16")), 16)
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return self_launch(args)
+    if args.workload == "dubrovnik":
+        return bench_dubrovnik(args)
+    rank, world, dev_index, red_dev, torch, dist = setup_ranks(args)
 
     from pose_estimation_amd import Context, shard, synth, SELECT_INLIERS, SAMPLE_BASIC
     ctx = Context(dev_index)
@@ -123,39 +175,20 @@ def main():
     if rank == 0:
         total_hyps = H * args.steps * world
         info = ctx.device_info()
-        # Roofline of the dominant kernel of the step.  Durations are HIP-event times taken by the
-        # library on its own stream around each kernel, averaged over the launches of the timed steps.
-        launches = max(int(tim["launches"]), 1)
         hyps_rank = H * args.steps
-        # large launches are scored by the matrix-core screen, small ones by the packed-float32 one
-        maxsol = 4 if args.known_focal else 10
-        score_kernel = ("k_score_mfma" if hyps_rank // launches * maxsol >= int(os.environ.get("POSE_AMD_MFMA_MIN_SLOTS", "8192")) and
-                        os.environ.get("POSE_AMD_SCORE") not in ("packed", "fp64") else "k_score_screen")
-        work = {"k_solve_p3p": (tim["solve_ms"], hyps_rank * P3P_FLOP_PER_HYP)} if args.known_focal else {}
-        work.update({"k_p4pf_elim": (tim["elim_ms"], hyps_rank * ELIM_FLOP_PER_HYP),
-                "k_p4pf_finish": (tim["finish_ms"], hyps_rank * FINISH_FLOP_PER_HYP),
-                score_kernel: (tim["score_ms"], poses * args.matches * SCORE_FLOP_PER_PAIR)})
-        dom = max(work, key=lambda k: work[k][0])
-        dom_ms, dom_flop = work[dom]
-        tflops = dom_flop / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
-        roofline = {"kernel": dom, "bound": "valu_fp64", "achieved": round(tflops, 3), "peak": FP64_VECTOR_PEAK_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(tflops / FP64_VECTOR_PEAK_TFLOPS, 4), "traffic": recorded_traffic(dom, hyps_rank / launches),
-                    "launches": launches, "avg_launch_ms": round(dom_ms / launches, 4),
-                    "kernel_ms_per_step": {k: round(v / args.steps, 3) for k, v in tim.items() if k.endswith("_ms")},
-                    "kernel_tflops": {k: round(f / (ms * 1e-3) / 1e12, 3) for k, (ms, f) in work.items() if ms > 0},
-                    "poses_per_hypothesis": round(poses / hyps_rank, 3)}
-        # the same kernel against the HBM roof (recorded HBM bytes per launch over the live duration):
-        # it is far from it, which is why the bound is stated as float64 vector arithmetic
-        if roofline["traffic"] and dom_ms > 0:
-            gbps = roofline["traffic"] / (dom_ms / launches * 1e-3) / 1e9
-            roofline["hbm"] = {"achieved": round(gbps, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(gbps / 8000.0, 4)}
-        out = {"metric": "RANSAC hypotheses/sec (%s solve+score)" % ("P3P" if args.known_focal else "P4Pf"), "value": round(total_hyps / dt, 1), "unit": "hypotheses/s",
+        launches = max(int(tim["launches"]), 1)
+        if args.known_focal:
+            tim["p3p_ms"] = tim["solve_ms"]
+        roofline = roofline_of(tim, hyps_rank, poses, args.matches, args.known_focal, launches, args.steps)
+        solver = "P3P" if args.known_focal else "P4Pf"
+        shape = ("BASELINE configs[0] shape: " if (args.matches, args.known_focal) == (2000, True) else
+                 "BASELINE configs[1]: " if (args.matches, args.inlier_frac, args.known_focal) == (4000, 0.10, False) else
+                 "BASELINE configs[4] shape: " if args.matches == 100000 else "")
+        out = {"metric": "RANSAC hypotheses/sec (%s solve+score)" % solver, "value": round(total_hyps / dt, 1), "unit": "hypotheses/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-               "config": {"workload": ("%s" + ("P3P" if args.known_focal else "P4Pf") + " RANSAC, single query, %d matches, %g%% inliers, %d hypotheses per GPU per step")
-                          % ("BASELINE configs[0] shape: " if (args.matches, args.known_focal) == (2000, True) else
-                             "BASELINE configs[1]: " if (args.matches, args.inlier_frac) == (4000, 0.10) else
-                             "BASELINE configs[4] shape: " if args.matches == 100000 else "", args.matches, args.inlier_frac * 100, H),
+               "config": {"workload": "%s%s RANSAC, single query, %d matches, %g%% inliers, %d hypotheses per GPU per step"
+                                      % (shape, solver, args.matches, args.inlier_frac * 100, H),
                           "select": "inlier count", "parallelism": "hypothesis range sharded over %d GPU(s)" % world,
                           "device": info["name"], "best_inliers": int(last["inliers"])},
                "roofline": roofline}
@@ -168,12 +201,131 @@ def main():
             ctx.synchronize()
             out["config"]["pcie_inclusive_hypotheses_per_s"] = round(2 * H / (time.perf_counter() - t1), 1)
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(ctx, q, args)
+            out["cpu_baseline"] = cpu_baseline_single(ctx, q, args)
         print(json.dumps(out))
     ctx.close()
     if world > 1:
         dist.destroy_process_group()
     return 0
+
+
+def roofline_of(tim, hyps, poses, matches_x_poses_or_n, known_focal, launches, steps):
+    """Roofline object of the dominant kernel.  `tim`: HIP-event times (ms) summed by the library
+    on its own stream around each kernel over `hyps` hypotheses and `poses` scored poses;
+    matches_x_poses_or_n: correspondences per query (single workload) or, for batches of queries of
+    different sizes, the summed (pose, correspondence) pairs as a float."""
+    pairs = matches_x_poses_or_n if isinstance(matches_x_poses_or_n, float) else poses * matches_x_poses_or_n
+    maxsol = 4 if known_focal else 10
+    per_launch_slots = hyps // max(launches, 1) * maxsol
+    score_kernel = ("k_score_mfma" if per_launch_slots >= int(os.environ.get("POSE_AMD_MFMA_MIN_SLOTS", "8192")) and
+                    os.environ.get("POSE_AMD_SCORE") not in ("packed", "fp64") else "k_score_screen")
+    work = {}
+    if tim.get("p3p_ms", 0) > 0:
+        work["k_solve_p3p"] = (tim["p3p_ms"], tim.get("p3p_hyps", hyps) * P3P_FLOP_PER_HYP)
+    if tim.get("elim_ms", 0) > 0:
+        ph = tim.get("p4pf_hyps", hyps)
+        work["k_p4pf_elim"] = (tim["elim_ms"], ph * ELIM_FLOP_PER_HYP)
+        work["k_p4pf_finish"] = (tim["finish_ms"], ph * FINISH_FLOP_PER_HYP)
+    work[score_kernel] = (tim["score_ms"], pairs * SCORE_FLOP_PER_PAIR)
+    dom = max(work, key=lambda k: work[k][0])
+    dom_ms, dom_flop = work[dom]
+    tflops = dom_flop / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
+    rec = recorded_counters(dom)
+    traffic = rec["hbm_bytes_per_hypothesis"] * hyps / launches if rec and "hbm_bytes_per_hypothesis" in rec else None
+    roofline = {"kernel": dom, "bound": "valu_fp64", "achieved": round(tflops, 3), "peak": FP64_VECTOR_PEAK_TFLOPS,
+                "unit": "TFLOP/s", "frac": round(tflops / FP64_VECTOR_PEAK_TFLOPS, 4), "traffic": traffic,
+                "traffic_source": rec.get("source") if rec else None,
+                "launches": launches, "avg_launch_ms": round(dom_ms / launches, 4),
+                "kernel_ms_per_step": {k: round(v / steps, 3) for k, v in tim.items() if k.endswith("_ms")},
+                "kernel_tflops": {k: round(f / (ms * 1e-3) / 1e12, 3) for k, (ms, f) in work.items() if ms > 0 and k != "k_score_mfma"},
+                "poses_per_hypothesis": round(poses / max(hyps, 1), 3)}
+    # executed float64 lane-operations (SQ_INSTS_VALU_*_F64 x 64 from the recorded counter passes)
+    # beside the algorithmic figure: the difference is idle lanes, pivots and retired rows
+    if rec and "executed_fp64_flop_per_hypothesis" in rec and dom_ms > 0:
+        ex = rec["executed_fp64_flop_per_hypothesis"] * (tim.get("p4pf_hyps", hyps) if dom.startswith("k_p4pf") else hyps) / (dom_ms * 1e-3) / 1e12
+        roofline["executed"] = {"tflops": round(ex, 3), "frac": round(ex / FP64_VECTOR_PEAK_TFLOPS, 4),
+                                "flop_per_hypothesis": rec["executed_fp64_flop_per_hypothesis"]}
+    if score_kernel == "k_score_mfma" and tim["score_ms"] > 0:
+        # The matrix-core screen does not do the float64 work of the algorithmic count: it certifies
+        # pairs outside with bf16 products and decides the few others in float64.  Its own roofs:
+        sec = tim["score_ms"] * 1e-3
+        mf = pairs * SCREEN_MFMA_FLOP_PER_PAIR / sec / 1e12
+        roofline["k_score_mfma"] = {"pairs_per_s": round(pairs / sec, 1),
+                                    "algorithmic_fp64_equivalent_tflops": round(pairs * SCORE_FLOP_PER_PAIR / sec / 1e12, 2),
+                                    "mfma_bf16": {"achieved": round(mf, 1), "peak": BF16_MFMA_PEAK_TFLOPS,
+                                                  "unit": "TFLOP/s", "frac": round(mf / BF16_MFMA_PEAK_TFLOPS, 4)},
+                                    "note": "vector pipe is its limiter (one fma + one compare per pair, queueing of uncertified pairs)"}
+        if dom == "k_score_mfma":
+            # the dominant kernel is the screen: state the roofline against the pipe it runs on
+            roofline.update({"bound": "mfma", "achieved": round(mf, 1), "peak": BF16_MFMA_PEAK_TFLOPS, "frac": round(mf / BF16_MFMA_PEAK_TFLOPS, 4),
+                             "executed": None})
+    if traffic and dom_ms > 0:
+        gbps = traffic / (dom_ms / launches * 1e-3) / 1e9
+        roofline["hbm"] = {"achieved": round(gbps, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbps / HBM_PEAK_GBS, 4)}
+    return roofline
+
+
+def recorded_counters(kernel):
+    """Per-hypothesis HBM bytes (FETCH_SIZE doubled as measured for gfx950, plus WRITE_SIZE) and
+    executed float64 lane-operations of `kernel` from the newest committed counter passes
+    (profiles/r*_traffic.json, collected with rocprofv3 --pmc on this benchmark); None when no
+    record exists.  Counters cannot be read inside the timed run itself."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")), reverse=True):
+        try:
+            with open(path) as f:
+                rec = json.load(f)
+            n = rec["hypotheses_per_launch"]
+            out = {"source": os.path.relpath(path, ROOT)}
+            if kernel in rec:
+                out["hbm_bytes_per_hypothesis"] = rec[kernel]["hbm_bytes_per_launch"] / n
+            ph = rec.get("_per_hypothesis", {}).get(kernel)
+            if ph:
+                out["executed_fp64_flop_per_hypothesis"] = ph["executed_fp64_lane_flop_per_hypothesis"]
+            if len(out) > 1:
+                return out
+        except (OSError, ValueError, KeyError):
+            continue
+    return None
+
+
+def cpu_baseline_single(ctx, q, args):
+    """The CPU oracle (a port of the reference's algorithm; the reference itself needs Eigen,
+    FLANN and OpenCV, which are not installed) on a bounded sample of the same workload: the
+    first `count` hypotheses of the benchmark's sample stream, OpenMP over hypotheses."""
+    import oracle_lib as O
+    from pose_estimation_amd import SAMPLE_BASIC
+    cores = host_cores()
+    kw = (q["kx"], q["ky"], q["X"], q["Y"], q["Z"], q["width"], q["height"], q["focal"])
+    probe = ctx.sample(SAMPLE_BASIC, 1002, 0, 0, 4096)
+    probe[:, 3] = np.where(probe[:, 3] == 0xFFFFFFFF, 0, probe[:, 3])
+    t0 = time.perf_counter()
+    O.ransac_fixed_budget(*kw, probe, threads=cores)
+    per = (time.perf_counter() - t0) / len(probe)
+    count = args.cpu_hyps or int(min(max(12.0 / max(per, 1e-8), 4096), 1 << 22))
+    samples = ctx.sample(SAMPLE_BASIC, 1002, 0, 0, count)
+    samples[:, 3] = np.where(samples[:, 3] == 0xFFFFFFFF, 0, samples[:, 3])
+    t0 = time.perf_counter()
+    O.ransac_fixed_budget(*kw, samples, threads=cores)
+    dt = time.perf_counter() - t0
+    # the reference's own shape of the loop: one step after the other on one core, coverage-quality selection
+    ns = min(len(samples), max(256, int(3.0 / max(per * cores, 1e-8))))
+    t1 = time.perf_counter()
+    O.ransac(*kw, samples[:ns], select_coverage=True, early_exit=False, max_steps=ns)
+    dts = time.perf_counter() - t1
+    # and as the reference executes it: 4 OpenMP threads inside projection / map painting, two h x w float maps per pose
+    nf = 300
+    t2 = time.perf_counter()
+    O.ransac_reference_faithful(*kw, samples[:nf], early_exit=False, max_steps=nf, threads=4)
+    dtf = time.perf_counter() - t2
+    return {"value": round(count / dt, 1), "unit": "hypotheses/s", "cores": cores, "cpu": cpu_model(), "kind": "port",
+            "sample": "first %d hypotheses of the same query and sample stream (tuples exported by the device sampler), "
+                      "oracle/pose_oracle.c with OpenMP over hypotheses, %.1f s" % (count, dt),
+            "serial_reference_loop": {"value": round(ns / dts, 1), "unit": "hypotheses/s", "cores": 1,
+                                      "sample": "first %d hypotheses, sequential loop with coverage-quality selection, %.1f s" % (ns, dts)},
+            "reference_faithful": {"value": round(nf / dtf, 1), "unit": "hypotheses/s", "cores": 4,
+                                   "sample": "first %d hypotheses, sequential loop, TestHypothesis as the reference runs it (OMP_NUM_THREADS=4 inside "
+                                             "projection and painting, two height x width float maps per pose), %.1f s" % (nf, dtf)}}
 
 
 def bench_dubrovnik(args):
@@ -183,21 +335,7 @@ def bench_dubrovnik(args):
     A step is one pass over all queries.  Each GPU is driven by a few host threads, one
     context (HIP stream) each, so that the small per-query launches of different queries overlap."""
     from concurrent.futures import ThreadPoolExecutor
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    import torch
-    dist = None
-    ndev = max(1, torch.cuda.device_count())
-    dev_index = local_rank % ndev
-    red_dev = f"cuda:{dev_index}" if args.backend == "nccl" else "cpu"
-    if world > 1:
-        import torch.distributed as dist
-        torch.cuda.set_device(dev_index)
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
-        else:
-            dist.init_process_group("gloo")
+    rank, world, dev_index, red_dev, torch, dist = setup_ranks(args)
     from pose_estimation_amd import Context, shard, synth, SELECT_INLIERS, SELECT_COVERAGE, SAMPLE_BASIC, SAMPLE_ADVANCED
     if args.advanced:
         args.budget, args.early_exit = 100, False
@@ -218,6 +356,7 @@ def bench_dubrovnik(args):
         queries.append((qi, q))
     T = max(1, args.host_threads)
     select = SELECT_COVERAGE if (args.early_exit or args.advanced) else SELECT_INLIERS
+    sample_mode = SAMPLE_ADVANCED if args.advanced else SAMPLE_BASIC
     # one pose_amd_ransac_batch call: T worker threads inside the library, one stream each
     batched = not args.python_threads
     os.environ["POSE_AMD_BATCH_LANES"] = str(T)
@@ -225,15 +364,17 @@ def bench_dubrovnik(args):
     for i, (qi, q) in enumerate(queries):
         q["query_id"] = qi
 
+    def run_one(ctx, qi, q):
+        ctx.set_query(q["kx"], q["ky"], q["X"], q["Y"], q["Z"], q["width"], q["height"], q["focal"])
+        if args.advanced:
+            ctx.set_camsets(q["cam_off"], q["cam_ids"])
+        ctx.sample(sample_mode, 3000, qi, 0, args.budget, export=False)
+        return ctx.ransac_run(select, 0.5, early_exit=args.early_exit)
+
     def run_part(t):
-        ctx = ctxs[t]
         out = []
         for qi, q in queries[t::T]:
-            ctx.set_query(q["kx"], q["ky"], q["X"], q["Y"], q["Z"], q["width"], q["height"], q["focal"])
-            if args.advanced:
-                ctx.set_camsets(q["cam_off"], q["cam_ids"])
-            ctx.sample(SAMPLE_ADVANCED if args.advanced else SAMPLE_BASIC, 3000, qi, 0, args.budget, export=False)
-            r = ctx.ransac_run(select, 0.5, early_exit=args.early_exit)
+            r = run_one(ctxs[t], qi, q)
             out.append((qi, r["steps"], r["inliers"], float(np.linalg.norm(r["C"] - q["C_true"])) if r["found"] else float("inf")))
         return out
 
@@ -252,7 +393,7 @@ def bench_dubrovnik(args):
     def one_pass(pool):
         res = []
         if batched:
-            return ctxs[0].ransac_batch(prep, SAMPLE_ADVANCED if args.advanced else SAMPLE_BASIC, seed=3000, budget=args.budget, select_mode=select,
+            return ctxs[0].ransac_batch(prep, sample_mode, seed=3000, budget=args.budget, select_mode=select,
                                         early_exit=args.early_exit, raw=True)
         for part in pool.map(run_part, range(T)):
             res.extend(part)
@@ -287,21 +428,51 @@ def bench_dubrovnik(args):
     if rank == 0:
         steps_total = sum(r[1] for r in res)
         located = sum(1 for r in res if r[3] < 2.0)
+        mode = ("advanced processor: co-occurrence sampling over camera sets, 100 steps, coverage quality" if args.advanced
+                else "reference loop: coverage quality, early exit, <= %d steps" % args.budget if args.early_exit
+                else "fixed budget of %d hypotheses per query, inlier-count selection" % args.budget)
         out = {"metric": "queries/sec (Dubrovnik-shaped batch, %s RANSAC)" % ("advanced" if args.advanced else "basic"), "value": round(nq * args.steps / dt, 1), "unit": "queries/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
                "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-               "config": {"workload": "BASELINE configs[2/3]: %d Dubrovnik6K-shaped queries (real image sizes, %d known / %d unknown focal), "
+               "config": {"workload": "BASELINE configs[%d]: %d Dubrovnik6K-shaped queries (real image sizes, %d known / %d unknown focal), "
                                       "4000-6000 matches, 10-40%% inliers, %s"
-                                      % (nq, sum(1 for i in range(nq) if shapes[i % len(shapes)][2] > 0),
-                                         sum(1 for i in range(nq) if shapes[i % len(shapes)][2] == 0),
-                                         "advanced processor: co-occurrence sampling over camera sets, 100 steps, coverage quality" if args.advanced
-                                         else "reference loop: coverage quality, early exit, <= %d steps" % args.budget if args.early_exit
-                                         else "fixed budget of %d hypotheses per query, inlier-count selection" % args.budget),
+                                      % (3 if args.advanced else 2, nq, sum(1 for i in range(nq) if shapes[i % len(shapes)][2] > 0),
+                                         sum(1 for i in range(nq) if shapes[i % len(shapes)][2] == 0), mode),
                           "parallelism": "queries partitioned over %d GPU(s), %s" % (world, "%d worker threads / streams per GPU inside pose_amd_ransac_batch" % T if batched
                                                                                       else "%d host threads (contexts) per GPU" % T),
                           "hypotheses_per_s": round(steps_total * args.steps / dt, 1),
                           "mean_steps_per_query": round(steps_total / max(len(res), 1), 1),
                           "queries_within_2_units_of_true_position": located}}
+        if world == 1:
+            # Per-kernel times of this workload: a profiling pass outside the timed region, one
+            # context with timing events, a sample of the queries one after the other.
+            prof = Context(dev_index)
+            tim = {}
+            hyps = poses = 0
+            pairs = 0.0
+            sample_q = queries[::max(1, len(queries) // 64)][:64]
+            for qi, q in sample_q:
+                run_one(prof, qi, q)                                   # warm the context's buffers
+            for qi, q in sample_q:
+                r = run_one(prof, qi, q)
+                t_ = prof.last_timing()
+                for k, v in t_.items():
+                    tim[k] = tim.get(k, 0.0) + v
+                if q["focal"] > 0:
+                    tim["p3p_ms"] = tim.get("p3p_ms", 0.0) + t_["solve_ms"]
+                    tim["p3p_hyps"] = tim.get("p3p_hyps", 0) + r["steps"]
+                else:
+                    tim["p4pf_hyps"] = tim.get("p4pf_hyps", 0) + r["steps"]
+                hyps += r["steps"]; poses += r["poses_scored"]; pairs += float(r["poses_scored"]) * len(q["kx"])
+            prof.close()
+            tim["select_coverage_ms"] = tim.pop("select_ms", 0.0)
+            rl = roofline_of(tim, hyps, poses, pairs, False, max(int(tim.get("launches", 1)), 1), len(sample_q))
+            rl["note"] = ("per-kernel HIP-event times of %d of the queries run one after the other on one stream (outside the timed region); "
+                          "kernel_ms_per_step is per query; speculative chunks make the kernels process more hypotheses than the steps counted"
+                          % len(sample_q))
+            out["roofline"] = rl
+            if not args.no_cpu_baseline:
+                out["cpu_baseline"] = cpu_baseline_batch(ctxs[0], queries, args, select, sample_mode)
         print(json.dumps(out))
     for c in ctxs:
         c.close()
@@ -310,48 +481,60 @@ def bench_dubrovnik(args):
     return 0
 
 
-def recorded_traffic(kernel, hyps_per_launch):
-    """HBM bytes per launch of `kernel` from the committed counter passes (FETCH_SIZE doubled
-    as measured for gfx950, plus WRITE_SIZE), scaled from the recorded launch size to this run's
-    hypotheses per launch; None when no record exists for it."""
-    path = os.path.join(ROOT, "profiles", "r1_traffic.json")
-    try:
-        with open(path) as f:
-            rec = json.load(f)
-        return rec[kernel]["hbm_bytes_per_launch"] * hyps_per_launch / rec["hypotheses_per_launch"]
-    except (OSError, ValueError, KeyError):
-        return None
-
-
-def cpu_baseline(ctx, q, args):
-    """The CPU oracle (a port of the reference's algorithm; the reference itself needs Eigen,
-    FLANN and OpenCV, which are not installed) on a bounded sample of the same workload: the
-    first `count` hypotheses of the benchmark's sample stream, OpenMP over hypotheses."""
+def cpu_baseline_batch(ctx, queries, args, select, sample_mode):
+    """The CPU oracle on a bounded sample of the same queries and the same tuples (exported by the
+    device sampler): all host cores over queries (each query's loop is sequential, as in the
+    reference), plus the reference-faithful mode (4 OpenMP threads inside TestHypothesis, two
+    h x w float maps per pose) on a few of them."""
+    from concurrent.futures import ThreadPoolExecutor
     import oracle_lib as O
-    from pose_estimation_amd import SAMPLE_BASIC
-    cores = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16")), 16)
-    kw = (q["kx"], q["ky"], q["X"], q["Y"], q["Z"], q["width"], q["height"], q["focal"])
-    probe = ctx.sample(SAMPLE_BASIC, 1002, 0, 0, 4096)
-    probe[:, 3] = np.where(probe[:, 3] == 0xFFFFFFFF, 0, probe[:, 3])
+    from pose_estimation_amd import SELECT_COVERAGE
+    cores = host_cores()
+    coverage = select == SELECT_COVERAGE
+
+    def tuples(qi, q):
+        ctx.set_query(q["kx"], q["ky"], q["X"], q["Y"], q["Z"], q["width"], q["height"], q["focal"])
+        if args.advanced:
+            ctx.set_camsets(q["cam_off"], q["cam_ids"])
+        s = ctx.sample(sample_mode, 3000, qi, 0, args.budget)
+        s[:, 3] = np.where(s[:, 3] == 0xFFFFFFFF, 0, s[:, 3])
+        return s
+
+    def run(item):
+        (qi, q), s = item
+        kw = (q["kx"], q["ky"], q["X"], q["Y"], q["Z"], q["width"], q["height"], q["focal"])
+        if not coverage:
+            O.ransac_fixed_budget(*kw, s, threads=1)
+            return len(s)
+        return O.ransac(*kw, s, select_coverage=True, early_exit=args.early_exit, max_steps=args.budget)["steps"]
+
+    # probe one query to size the sample for about 10 s of CPU work
+    probe = (queries[0], tuples(*queries[0]))
     t0 = time.perf_counter()
-    O.ransac_fixed_budget(*kw, probe, threads=cores)
-    per = (time.perf_counter() - t0) / len(probe)
-    count = args.cpu_hyps or int(min(max(15.0 / max(per, 1e-8), 4096), 1 << 22))
-    samples = ctx.sample(SAMPLE_BASIC, 1002, 0, 0, count)
-    samples[:, 3] = np.where(samples[:, 3] == 0xFFFFFFFF, 0, samples[:, 3])
+    run(probe)
+    per = time.perf_counter() - t0
+    count = int(min(len(queries), max(cores, 10.0 * cores / max(per, 1e-6))))
+    items = [(qq, tuples(*qq)) for qq in queries[:count]]
     t0 = time.perf_counter()
-    O.ransac_fixed_budget(*kw, samples, threads=cores)
+    with ThreadPoolExecutor(cores) as pool:
+        steps = sum(pool.map(run, items))
     dt = time.perf_counter() - t0
-    # the reference's own shape of the loop: one step after the other on one core, coverage-quality selection
-    ns = min(len(samples), max(256, int(4.0 / max(per * cores, 1e-8))))
-    t1 = time.perf_counter()
-    O.ransac(*kw, samples[:ns], select_coverage=True, early_exit=False, max_steps=ns)
-    dts = time.perf_counter() - t1
-    return {"value": round(count / dt, 1), "unit": "hypotheses/s", "cores": cores, "kind": "port",
-            "sample": "first %d hypotheses of the same query and sample stream (tuples exported by the device sampler), "
-                      "oracle/pose_oracle.c with OpenMP over hypotheses, %.1f s" % (count, dt),
-            "serial_reference_loop": {"value": round(ns / dts, 1), "unit": "hypotheses/s", "cores": 1,
-                                      "sample": "first %d hypotheses, sequential loop with coverage-quality selection, %.1f s" % (ns, dts)}}
+    out = {"value": round(count / dt, 2), "unit": "queries/s", "cores": cores, "cpu": cpu_model(), "kind": "port",
+           "hypotheses_per_s": round(steps / dt, 1),
+           "sample": "the first %d of the queries on the same tuples (exported by the device sampler), oracle/pose_oracle.c, one sequential "
+                     "loop per query, %d queries at a time, %.1f s" % (count, cores, dt)}
+    if coverage:
+        nf = 3
+        t1 = time.perf_counter()
+        fsteps = 0
+        for (qi, q), s in items[:nf]:
+            kw = (q["kx"], q["ky"], q["X"], q["Y"], q["Z"], q["width"], q["height"], q["focal"])
+            fsteps += O.ransac_reference_faithful(*kw, s[:min(len(s), 600)], early_exit=args.early_exit, max_steps=min(args.budget, 600), threads=4)["steps"]
+        dtf = time.perf_counter() - t1
+        out["reference_faithful"] = {"value": round(nf / dtf, 3), "unit": "queries/s", "cores": 4, "hypotheses_per_s": round(fsteps / dtf, 1),
+                                     "sample": "the first %d queries (at most 600 steps each), TestHypothesis as the reference runs it "
+                                               "(OMP_NUM_THREADS=4, two height x width float maps per pose), %.1f s" % (nf, dtf)}
+    return out
 
 
 if __name__ == "__main__":

@@ -314,6 +314,64 @@ int orc_sample_advanced(uint64_t seed, uint32_t query, uint32_t hyp, int m, uint
 /* RANSAC loop (query_processor_basic.cpp:105-293; advanced variant differs only in       */
 /* max_steps / early_exit, query_processor_advanced.cpp:296-327,445-581)                  */
 /* ===================================================================================== */
+/* TestHypothesis the way the reference executes it (query_processor.cpp:88-177), for timing the
+ * CPU path as it ships: Project over the matches with an OpenMP parallel for, a serial inlier
+ * loop, then two height x width float maps allocated and zeroed for EVERY pose, boxes painted
+ * by parallel loops, both maps summed, quality = float ratio.  Same results as orc_score +
+ * orc_coverage_area; only the cost differs.  Returns the inlier count. */
+static int test_hypothesis_faithful(const orc_query *q, const double P[12], double eps, int threads, uint8_t *mask, float *quality,
+                                    int64_t *area_fit, int64_t *area_all)
+{
+    const int n = q->n, width = q->width, height = q->height;
+    double *proj2d = (double *)malloc((size_t)n * 2 * sizeof(double));
+    (void)threads;
+#ifdef _OPENMP
+#pragma omp parallel for num_threads(threads)
+#endif
+    for (int i = 0; i < n; ++i) {                                                  /* Project, :59-83 */
+        double x = q->X[i], y = q->Y[i], z = q->Z[i];
+        double p0 = P[0] * x + P[1] * y + P[2] * z + P[3] * 1.0;
+        double p1 = P[4] * x + P[5] * y + P[6] * z + P[7] * 1.0;
+        double p2 = P[8] * x + P[9] * y + P[10] * z + P[11] * 1.0;
+        proj2d[2 * i] = p0 / p2; proj2d[2 * i + 1] = p1 / p2;
+    }
+    int count = 0;
+    for (int i = 0; i < n; ++i) {                                                  /* :103-124 */
+        double u = -(q->kx[i] - (double)width / 2.0), v = -(q->ky[i] - (double)height / 2.0);
+        double du = u - proj2d[2 * i], dv = v - proj2d[2 * i + 1];
+        int in = sqrt(du * du + dv * dv) < eps;
+        mask[i] = (uint8_t)in;
+        count += in;
+    }
+    free(proj2d);
+    float *fit = (float *)calloc((size_t)width * height, sizeof(float));           /* :129-133 */
+    float *all = (float *)calloc((size_t)width * height, sizeof(float));
+    const int cover = (int)ceilf((float)width / 20.0f);
+#define CLAMP(v, hi) ((v) < 0 ? 0 : ((v) > (hi) ? (hi) : (v)))
+    for (int pass = 0; pass < 2; ++pass) {                                         /* :137-169 */
+        float *map = pass ? all : fit;
+#ifdef _OPENMP
+#pragma omp parallel for num_threads(threads)
+#endif
+        for (int i = 0; i < n; ++i) {
+            if (!pass && !mask[i]) continue;
+            int x = (int)rintf(q->kx[i]), y = (int)rintf(q->ky[i]);
+            int sx = CLAMP(x - cover / 2, width - 1), sy = CLAMP(y - cover / 2, height - 1);
+            int ex = CLAMP(x + cover / 2, width - 1), ey = CLAMP(y + cover / 2, height - 1);
+            if (sy < ey && sx < ex)
+                for (int r = sy; r < ey; ++r)
+                    for (int c = sx; c < ex; ++c) map[(size_t)r * width + c] = 1.0f;
+        }
+    }
+#undef CLAMP
+    float sf = 0.0f, sa = 0.0f;                                                     /* :171-174; sums of ones are exact in float up to 2^24 */
+    for (size_t i = 0; i < (size_t)width * height; ++i) { sf += fit[i]; sa += all[i]; }
+    free(fit); free(all);
+    *quality = sf / sa;
+    *area_fit = (int64_t)sf; *area_all = (int64_t)sa;
+    return count;
+}
+
 /* The state the reference's loop carries from one step to the next, and across the
  * backmatching reset (query_processor_advanced.cpp:597-602 resets `steps` only). */
 typedef struct {
@@ -324,8 +382,18 @@ typedef struct {
 
 /* One run of the while loop over the given tuples.  Returns the steps executed; a kept pose
  * is written to res (with res->best_step relative to this run) and *kept is set. */
+static unsigned ransac_loop_ex(const orc_query *q, const orc_ransac_params *p, const uint32_t *samples, unsigned nsamples,
+                               loop_state *st, orc_ransac_result *res, uint8_t *best_mask, int *kept, int faithful_threads);
 static unsigned ransac_loop(const orc_query *q, const orc_ransac_params *p, const uint32_t *samples, unsigned nsamples,
                             loop_state *st, orc_ransac_result *res, uint8_t *best_mask, int *kept)
+{
+    return ransac_loop_ex(q, p, samples, nsamples, st, res, best_mask, kept, 0);
+}
+
+/* faithful_threads > 0: every pose goes through test_hypothesis_faithful with that many OpenMP
+ * threads (coverage selection only). */
+static unsigned ransac_loop_ex(const orc_query *q, const orc_ransac_params *p, const uint32_t *samples, unsigned nsamples,
+                               loop_state *st, orc_ransac_result *res, uint8_t *best_mask, int *kept, int faithful_threads)
 {
     int p4pfmode = q->focal == 0.0;
     unsigned hyposet = st->hyposet, steps = 0;
@@ -372,11 +440,17 @@ static unsigned ransac_loop(const orc_query *q, const orc_ransac_params *p, cons
         for (int k = 0; k < nsol; ++k) {
             double P[12];
             orc_compute_matrices(fs[k], Cs + 3 * k, Rcs + 9 * k, P);
-            int cnt = orc_score(P, q->n, q->kx, q->ky, q->X, q->Y, q->Z, q->width, q->height, p->eps, mask);
             res->poses_scored++;
             int better;
             int64_t key;
-            if (p->select_coverage) {
+            int cnt;
+            if (faithful_threads > 0 && p->select_coverage) {
+                float qf;
+                int64_t aall;
+                cnt = test_hypothesis_faithful(q, P, p->eps, faithful_threads, mask, &qf, &key, &aall);
+                better = (double)qf > hypoquality;
+                if (better) hypoquality = (double)qf;
+            } else if ((cnt = orc_score(P, q->n, q->kx, q->ky, q->X, q->Y, q->Z, q->width, q->height, p->eps, mask)), p->select_coverage) {
                 key = cnt > 0 ? orc_coverage_area(q->n, q->kx, q->ky, mask, q->width, q->height) : 0;
                 float qf = (float)key / (float)area_all;                         /* query_processor.cpp:171-174 */
                 better = (double)qf > hypoquality;
@@ -401,6 +475,16 @@ static unsigned ransac_loop(const orc_query *q, const orc_ransac_params *p, cons
     st->hyposet = hyposet; st->hypoquality = hypoquality; st->best_key = best_key;
     free(mask);
     return steps;
+}
+
+int orc_ransac_reference_faithful(const orc_query *q, const orc_ransac_params *p, const uint32_t *samples, unsigned nsamples,
+                                  int threads, orc_ransac_result *res)
+{
+    memset(res, 0, sizeof *res);
+    loop_state st = {0, 0.0, 0};
+    res->area_all = p->select_coverage ? orc_coverage_area(q->n, q->kx, q->ky, NULL, q->width, q->height) : 0;
+    res->steps = ransac_loop_ex(q, p, samples, nsamples, &st, res, NULL, NULL, threads > 0 ? threads : 1);
+    return 0;
 }
 
 int orc_ransac(const orc_query *q, const orc_ransac_params *p, const uint32_t *samples, unsigned nsamples,

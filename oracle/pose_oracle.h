@@ -112,6 +112,12 @@ typedef struct {
 int orc_ransac(const orc_query *q, const orc_ransac_params *p, const uint32_t *samples,
                unsigned nsamples, orc_ransac_result *res, uint8_t *best_mask);
 
+/* orc_ransac with TestHypothesis executed the way the reference executes it (OpenMP inside the
+ * projection and the map painting only, two height x width float maps per pose): the
+ * reference-faithful CPU timing mode.  Results equal orc_ransac's (coverage selection). */
+int orc_ransac_reference_faithful(const orc_query *q, const orc_ransac_params *p, const uint32_t *samples, unsigned nsamples,
+                                  int threads, orc_ransac_result *res);
+
 /* The advanced processor's loop with its backmatching leg (query_processor_advanced.cpp:296-327,
  * 583-606).  q1: good_matches before, q2: after Backmatching appended its matches (NULL: no
  * backmatching available).  The second leg runs once, only if the kept pose of the first has

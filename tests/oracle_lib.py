@@ -60,6 +60,7 @@ def load():
     lib.orc_sample_advanced.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_int, C.c_uint32, _up, _up, _up, _up,
                                         C.POINTER(C.c_int)]
     lib.orc_ransac.argtypes = [C.POINTER(OrcQuery), C.POINTER(OrcParams), _up, C.c_uint, C.POINTER(OrcResult), _bp]
+    lib.orc_ransac_reference_faithful.argtypes = [C.POINTER(OrcQuery), C.POINTER(OrcParams), _up, C.c_uint, C.c_int, C.POINTER(OrcResult)]
     lib.orc_ransac_fixed_budget.argtypes = [C.POINTER(OrcQuery), C.c_double, _up, C.c_uint, C.c_int, C.POINTER(C.c_uint64)]
     lib.orc_ransac_fixed_budget.restype = C.c_uint64
     return lib
@@ -185,6 +186,18 @@ def _result_dict(res):
     return dict(found=res.found, focal=res.focal, C=np.array(res.C[:]), Rc=np.array(res.Rc[:]).reshape(3, 3),
                 hyposet=res.hyposet, area_fit=res.area_fit, area_all=res.area_all, steps=res.steps,
                 best_step=res.best_step, best_sol=res.best_sol, poses_scored=res.poses_scored)
+
+
+def ransac_reference_faithful(kx, ky, X, Y, Z, width, height, focal, samples, eps=0.5, max_steps=10000, early_exit=True, threads=4):
+    """The sequential loop with TestHypothesis executed as the reference executes it (two h x w
+    float maps per pose, OpenMP inside projection and painting only): the CPU timing mode that
+    mirrors the shipped reference.  Same result fields as ransac()."""
+    q = OrcQuery(len(kx), _p(kx, _fp), _p(ky, _fp), _p(X, _fp), _p(Y, _fp), _p(Z, _fp), width, height, float(focal))
+    p = OrcParams(1, eps, max_steps, 10, 12, int(early_exit))
+    s = np.ascontiguousarray(samples, dtype=np.uint32)
+    res = OrcResult()
+    lib().orc_ransac_reference_faithful(C.byref(q), C.byref(p), _p(s, _up), len(s), int(threads), C.byref(res))
+    return _result_dict(res)
 
 
 def ransac_backmatch(q1, q2, samples1, samples2, select_coverage=True, eps=0.5, max_steps=100, early_exit=False):

@@ -353,3 +353,16 @@ def test_advanced_sampler_fixture():
     for h, (t, st, npr) in enumerate(zip(fx["tuples"], fx["status"], fx["prob_draws"])):
         got, gst, gnp = O.sample_advanced(fx["seed"], fx["query_id"], h, 4, fx["n"], off, ids)
         assert [int(v) for v in got] == t and gst == st and gnp == npr
+
+
+def test_reference_faithful_timing_mode_gives_the_same_loop():
+    """The CPU timing mode that executes TestHypothesis as the reference does (two h x w float maps
+    per pose, OpenMP inside projection and painting) must return what the plain oracle loop returns."""
+    q = synth.make_query(800, 0.3, 5, width=640, height=480, focal=500.0)
+    a = (q["kx"], q["ky"], q["X"], q["Y"], q["Z"], q["width"], q["height"], 0.0)
+    s = np.array([O.sample_basic(9, 0, h, 4, 800)[0] for h in range(60)], np.uint32)
+    for early in (True, False):
+        r1 = O.ransac(*a, s, select_coverage=True, early_exit=early, max_steps=60)
+        r2 = O.ransac_reference_faithful(*a, s, early_exit=early, max_steps=60, threads=2)
+        for k in ("found", "steps", "best_step", "best_sol", "hyposet", "area_fit", "area_all", "poses_scored"):
+            assert r1[k] == r2[k], k
