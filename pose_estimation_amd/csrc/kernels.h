@@ -359,7 +359,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     __shared__ double cf[ELIM_BATCH][43];
     __shared__ int st_s[ELIM_BATCH];
     __shared__ uint4 tab[32 * ELIM_TAB_VEC];
-    __shared__ double2 pbuf[4][17];      // 17: the four rows of 16 lanes read their 16-byte entries from different banks
+    __shared__ double2 pbuf[4][ELIM_PBUF_VEC];   // per row of 16 lanes: the published pivot rows of a block; the odd stride keeps the four systems on different banks
     const int lane = threadIdx.x;
     for (int i = lane; i < 32 * ELIM_TAB_VEC; i += 64) tab[i] = reinterpret_cast<const uint4 *>(c_elim_tab)[i];
     const uint32_t nbatch = (hyp_count + batch - 1) / batch;

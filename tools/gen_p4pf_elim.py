@@ -36,7 +36,8 @@ RHS = list(range(78, 88))
 QUAD_BCAST = os.environ.get("P4PF_ELIM_QUAD_BCAST", "lds")   # pivot-row broadcast: "lds" (write + broadcast read) or "bpermute"
 SKIP = os.environ.get("P4PF_ELIM_SKIP", "")    # timing experiments only: "stage1" or "stage2" leaves that stage out
 PREFETCH = int(os.environ.get("P4PF_ELIM_PREFETCH", "0"))     # stage-1 steps between an LDS read and its first use (0..8 measured the same)
-FAKE_BLOCK = int(os.environ.get("P4PF_ELIM_FAKE_BLOCK", "0"))   # timing experiment only (wrong results): publish the pivot row every n-th step only
+ROW_BYTES = 320          # LDS bytes per published pivot row of a block (40 doubles); 320 mod 256 = 64 keeps the rows of a block on different banks
+BLOCK = int(os.environ.get("P4PF_ELIM_BLOCK", "4"))      # stage-2 steps per block of delayed updates (0: one pivot row published per step)
 QUAD_CHUNK = int(os.environ.get("P4PF_ELIM_QUAD_CHUNK", "16"))   # pivot-row entries in flight per group of broadcasts
 
 
@@ -259,6 +260,110 @@ def simulate(sched, k):
     return 0, A
 
 
+def stage2_blocks(sched, block):
+    """Partition of the stage-2 steps: the leading in-lane steps stay single; the others are
+    taken `block` at a time.  Per block: its steps, its own columns and the trailing columns
+    (every column one of its pivot rows can hold, minus the block's own)."""
+    st2 = sched["stage2"]
+    lead = [i for i, st in enumerate(st2) if st.get("in_lane")]
+    rest = [i for i in range(len(st2)) if i not in lead]
+    blocks = []
+    for b0 in range(0, len(rest), block):
+        idx = rest[b0:b0 + block]
+        cols = [st2[i]["col"] for i in idx]
+        trail = sorted(set().union(*[set(st2[i]["pattern"]) for i in idx]) - set(cols))
+        blocks.append(dict(steps=idx, cols=cols, trail=trail))
+    return lead, blocks
+
+
+def simulate_blocked(sched, k, block=4):
+    """NumPy model of the blocked stage 2 the kernel runs: inside a block only the block's own
+    columns are kept current (panel); the pivot rows' trailing entries are published raw at the
+    end of the block, every row folds the block's multipliers into effective ones
+    (m' = m L^-1, L = unit lower triangle of the multipliers the pivot rows received inside the
+    block) and applies all pivots of the block to its trailing entries at once."""
+    lanes_rows = sched["lanes_rows"]
+    nl = len(lanes_rows)
+    R = np.zeros((nl, 88))
+    for li, r in enumerate(lanes_rows):
+        for c, g in sched["orig"][r].items():
+            R[li, c] = k[g]
+    for st in sched["steps"]:
+        pc, pv = st["col"], st["pv"]
+        m = R[:, pc] / pv
+        vals = {c2: k[sched["orig"][st["row"]][c2]] for c2 in st["pattern"]}
+        for c2 in st["pattern"]:
+            R[:, c2] -= m * vals[c2]
+        R[:, pc] = 0.0
+    active = np.zeros(nl, bool)
+    for r in sched["survivors"]:
+        active[sched["lane_of"][r]] = True
+    lead, blocks = stage2_blocks(sched, block)
+    for i in lead:                                   # single steps, as in simulate()
+        st = sched["stage2"][i]
+        c = st["col"]
+        cand = np.where(active, np.abs(R[:, c]), -1.0)
+        L = int(np.argmax(cand))
+        if cand[L] <= 0.0:
+            return -1, None
+        m = np.where(active, R[:, c] / R[L, c], 0.0)
+        m[L] = 0.0
+        for c2 in st["pattern"]:
+            R[:, c2] -= m * R[L, c2]
+        R[:, c] = 0.0
+        active[L] = False
+    for blk in blocks:
+        nb = len(blk["cols"])
+        M = np.zeros((nl, nb))                      # multipliers (update is  row += m * pivot row)
+        piv = []
+        for kk, c in enumerate(blk["cols"]):
+            cand = np.where(active, np.abs(R[:, c]), -1.0)
+            L = int(np.argmax(cand))
+            if cand[L] <= 0.0:
+                return -1, None
+            M[:, kk] = np.where(active, -R[:, c] / R[L, c], 0.0)
+            M[L, kk] = 0.0
+            for c2 in blk["cols"][kk + 1:]:         # panel: the block's later columns stay current
+                R[:, c2] += M[:, kk] * R[L, c2]
+            active[L] = False
+            piv.append(L)
+        P = R[piv][:, blk["trail"]].copy()          # raw trailing rows of the pivots, as published
+        Lm = np.array([[M[piv[j], kk] if kk < j else 0.0 for kk in range(nb)] for j in range(nb)])
+        Me = M.copy()                               # effective multipliers: back substitution of m' L = m
+        for kk in range(nb - 2, -1, -1):
+            for j in range(kk + 1, nb):
+                Me[:, kk] += Me[:, j] * Lm[j, kk]
+        upd = Me @ P
+        mask = np.ones(nl, bool)
+        mask[piv] = False                           # retired rows are never read again
+        R[np.ix_(mask, blk["trail"])] += upd[mask]
+        for c in blk["cols"]:
+            R[:, c] = 0.0
+    pivot_lane = {}
+    pool = active.copy()
+    for c in KEEP:
+        cand = np.where(pool, np.abs(R[:, c]), -1.0)
+        L = int(np.argmax(cand))
+        if cand[L] <= 0.0:
+            return -1, None
+        pv = R[L, c]
+        m = np.where(active, R[:, c] / pv, 0.0)
+        m[L] = 0.0
+        for c2 in KEEP + RHS:
+            if c2 != c:
+                R[:, c2] -= m * R[L, c2]
+        R[:, c] = np.where(np.arange(nl) == L, R[:, c], 0.0)
+        pool[L] = False
+        pivot_lane[c] = L
+    A = np.zeros((5, 10))
+    for i in range(5, 10):
+        c = 79 - i
+        L = pivot_lane[c]
+        for j in range(10):
+            A[i - 5, j] = -R[L, 78 + 9 - j] / R[L, c]
+    return 0, A
+
+
 # ---------------------------------------------------------------------------------------------
 # HIP code generation
 # ---------------------------------------------------------------------------------------------
@@ -342,9 +447,7 @@ def emit(sched):
     m0 = sum(1 << L for L in surv if L < 16)
     m1 = sum(1 << (L - 16) for L in surv if L >= 16)
     w(f"    bool act0 = ((0x{m0:x}u >> rl) & 1u) != 0, act1 = ((0x{m1:x}u >> rl) & 1u) != 0;")
-    for si, st in enumerate(sched["stage2"]):
-        if SKIP in ("stage2", "both"):
-            break
+    def emit_single(si, st):
         c = st["col"]
         for s in (0, 1):
             need(c, s)
@@ -397,8 +500,7 @@ def emit(sched):
                 a_, b_ = pr[0], pr[-1]
                 w(f"        const v2f64 s{a_} = {{sl ? r{a_}_1 : r{a_}_0, sl ? r{b_}_1 : r{b_}_0}};")
             w("        const unsigned long long wm = __builtin_amdgcn_ballot_w64(lane == L);")
-            if not (FAKE_BLOCK and (si - 2) % FAKE_BLOCK != FAKE_BLOCK - 1):
-                masked_writes("wm", lambda pr: f"s{pr[0]}")
+            masked_writes("wm", lambda pr: f"s{pr[0]}")
             w("        __builtin_amdgcn_wave_barrier();")
             for i0 in range(0, len(pairs), QUAD_CHUNK // 2):
                 chunk = pairs[i0:i0 + QUAD_CHUNK // 2]
@@ -412,6 +514,117 @@ def emit(sched):
         w("        act0 = act0 && !(lane == L && !sl);")
         w("        act1 = act1 && !(lane == L && sl);")
         w("    }")
+
+    def emit_block(bi, blk):
+        """A block of delayed updates: panel steps on the block's own columns, then every pivot
+        row's raw trailing entries (and the multipliers it received inside the block) go to LDS in
+        one round of stores, and all rows apply the whole block at once."""
+        st2 = sched["stage2"]
+        cols, trail, nb = blk["cols"], blk["trail"], len(blk["cols"])
+        for c in cols + trail:
+            need(c, 0)
+            need(c, 1)
+        npadL = 0 if nb == 1 else 2 * ((nb - 1 + 1) // 2)          # doubles reserved for the L entries at the head of a row
+        w(f"    {{ // stage 2 block {bi}: columns {cols}, {len(trail)} trailing columns")
+        w("        int pk = -1, pk2 = -1;            // this lane's first / second pivot inside the block")
+        w("        bool psl = false;                 // slot of the first one")
+        for k, c in enumerate(cols):
+            w(f"        // step {blk['steps'][k]}: column {c}")
+            w(f"        bool sl{k}, none{k};")
+            w(f"        const int L{k} = row16_argmax_abs(r{c}_0, act0, r{c}_1, act1, sl{k}, none{k});")
+            w(f"        bad |= none{k};")
+            w(f"        const double nr{k} = neg_rcp(lane_bcast(sl{k} ? r{c}_1 : r{c}_0, L{k}));")
+            # retired rows are never read again: no masking of their multipliers
+            w(f"        double m{k}_0 = r{c}_0 * nr{k}, m{k}_1 = r{c}_1 * nr{k};")
+            for c2 in cols[k + 1:]:
+                w(f"        {{ const double e = lane_bcast(sl{k} ? r{c2}_1 : r{c2}_0, L{k});")
+                w(f"          r{c2}_0 = fma(m{k}_0, e, r{c2}_0); r{c2}_1 = fma(m{k}_1, e, r{c2}_1); }}")
+            w(f"        {{ const bool me = lane == L{k};")
+            w(f"          pk2 = me && pk >= 0 ? {k} : pk2; psl = me && pk < 0 ? sl{k} : psl; pk = me && pk < 0 ? {k} : pk;")
+            w(f"          act0 = act0 && !(me && !sl{k}); act1 = act1 && !(me && sl{k}); }}")
+        # ---- publish: one masked round of stores for every lane's first pivot of the block
+        items = []                                  # doubles of a row, in order: L entries, padding, trailing entries
+        for k in range(nb - 1):
+            items.append(("m", k))
+        while len(items) < npadL:
+            items.append(("z", 0))
+        for c in trail:
+            items.append(("r", c))
+        if len(items) % 2:
+            items.append(("z", 0))
+        npairs = len(items) // 2
+        assert npairs * 16 <= ROW_BYTES, (npairs, ROW_BYTES)
+
+        def val(it, other):
+            kind, x = it
+            a, b = ("0", "1") if other else ("1", "0")
+            if kind == "z":
+                return "0.0"
+            if kind == "m":
+                return f"(psl ? m{x}_{a} : m{x}_{b})"
+            return f"(psl ? r{x}_{a} : r{x}_{b})"
+
+        def round_of_stores(tag, other, pkvar):
+            for j in range(npairs):
+                w(f"        const v2f64 {tag}{j} = {{{val(items[2 * j], other)}, {val(items[2 * j + 1], other)}}};")
+            w(f"        const unsigned long long wm{tag} = __builtin_amdgcn_ballot_w64({pkvar} >= 0);")
+            w(f"        const unsigned addr{tag} = pbuf_addr + (unsigned)({pkvar} < 0 ? 0 : {pkvar}) * {ROW_BYTES}u;")
+            for g0 in range(0, npairs, 6):
+                grp = list(range(g0, min(g0 + 6, npairs)))
+                lines = ['"s_mov_b64 exec, %[mask]\\n\\t"']
+                for j in grp:
+                    lines.append(f'"ds_write_b128 %[addr], %[a{j - g0}] offset:{16 * j}\\n\\t"')
+                lines.append('"s_mov_b64 exec, -1"')
+                w("        asm volatile(" + "\n                     ".join(lines))
+                ops = ", ".join(f'[a{j - g0}] "v"({tag}{j})' for j in grp)
+                w(f'                     :: [mask] "s"(wm{tag}), [addr] "v"(addr{tag}), {ops} : "memory");')
+
+        round_of_stores("pa", False, "pk")
+        # a lane whose two rows both became pivots inside this block publishes the second one in a
+        # round of its own; taken only when some lane of the wave needs it
+        w("        if (__builtin_amdgcn_ballot_w64(pk2 >= 0) != 0ull) {")
+        round_of_stores("pb", True, "pk2")
+        w("        }")
+        w("        __builtin_amdgcn_wave_barrier();")
+        # ---- effective multipliers m' = m L^-1 (back substitution), L from the pivot rows' heads
+        if nb > 1:
+            for j in range(1, nb):
+                for h in range((j + 1) // 2):
+                    w(f"        const double2 l{j}_{h} = pbuf[{(j * ROW_BYTES) // 16 + h}];")
+
+            def lref(j, k):
+                return f"l{j}_{k // 2}.{'xy'[k % 2]}"
+            for k in range(nb - 2, -1, -1):
+                for j in range(k + 1, nb):
+                    w(f"        m{k}_0 = fma(m{j}_0, {lref(j, k)}, m{k}_0); m{k}_1 = fma(m{j}_1, {lref(j, k)}, m{k}_1);")
+        # ---- apply the block to the trailing columns
+        first = npadL // 2                          # pair index of the first trailing pair
+        tpairs = [trail[i:i + 2] for i in range(0, len(trail), 2)]
+        CH = 2
+        for i0 in range(0, len(tpairs), CH):
+            chunk = list(range(i0, min(i0 + CH, len(tpairs))))
+            for i in chunk:
+                for k in range(nb):
+                    w(f"        const double2 p{k}_{i} = pbuf[{(k * ROW_BYTES) // 16 + first + i}];")
+            for i in chunk:
+                for c2, comp in zip(tpairs[i], "xy"):
+                    for k in range(nb):
+                        w(f"        r{c2}_0 = fma(m{k}_0, p{k}_{i}.{comp}, r{c2}_0);")
+                    for k in range(nb):
+                        w(f"        r{c2}_1 = fma(m{k}_1, p{k}_{i}.{comp}, r{c2}_1);")
+        w("        __builtin_amdgcn_wave_barrier();")
+        w("    }")
+
+    if SKIP not in ("stage2", "both"):
+        if BLOCK > 0:
+            lead, blocks = stage2_blocks(sched, BLOCK)
+            for i in lead:
+                emit_single(i, sched["stage2"][i])
+            for bi, blk in enumerate(blocks):
+                emit_block(bi, blk)
+        else:
+            for si, st in enumerate(sched["stage2"]):
+                emit_single(si, st)
     for c in KEEP + RHS:
         need(c, 0)
         need(c, 1)
@@ -439,6 +652,7 @@ def emit(sched):
     nvec = (max(len(order[0]), len(order[1])) + 15) // 16 + 1     # + 1: the look-ahead fetch of the id vectors
     head = ["// GENERATED by tools/gen_p4pf_elim.py -- do not edit.", "#pragma once", "namespace pose_amd {",
             f"constexpr int ELIM_TAB_VEC = {nvec};   // 16-byte vectors of coefficient ids per (slot, position)",
+            f"constexpr int ELIM_PBUF_VEC = {max(BLOCK, 1) * ROW_BYTES // 16 + 1};   // 16-byte vectors of LDS scratch per system: the published pivot rows of a block, + 1 so that the four systems of a wave sit on different banks",
             "// coefficient ids [slot * 16 + position][order of first use] of the initial matrix; 42 = structural zero",
             f"__constant__ __attribute__((aligned(16))) unsigned char c_elim_tab[32 * {nvec * 16}] = {{"]
     for s in (0, 1):
