@@ -169,6 +169,26 @@ typedef struct {
 int pose_amd_ransac_batch(pose_amd_ctx *ctx, int nq, const pose_amd_query *queries, int sample_mode, uint64_t seed,
                           uint32_t budget, const pose_amd_params *params, pose_amd_result *results);
 
+/* ---- several GPUs of one node from one host process (the loop of benchmark.cpp:24 over devices) -- */
+/* Assignment of queries to `nparts` parts by descending cost (match count), each to the least
+ * loaded part so far; deterministic.  part_of[nq].  Pure host code. */
+int pose_amd_partition_queries(int nq, const int *costs, int nparts, int *part_of);
+/* pose_amd_ransac_batch over the listed devices (a device may be listed more than once): the
+ * queries are partitioned as above, one host thread per listed device runs its share on a
+ * context of its own (created on first use, kept until pose_amd_multi_release), results come back
+ * in query order and equal the single-device call's.  No data moves between devices. */
+int pose_amd_ransac_batch_multi(const int *devices, int ndev, int nq, const pose_amd_query *queries, int sample_mode,
+                                uint64_t seed, uint32_t budget, const pose_amd_params *params, pose_amd_result *results);
+const char *pose_amd_multi_last_error(void);
+void pose_amd_multi_release(void);
+/* One share of a hypothesis-sharded query (a very large query split by hypothesis range over
+ * GPUs or ranks): evaluates ids [hyp_begin, hyp_begin + hyp_count) of the query's sample stream
+ * with inlier-count selection and returns the packed key (inliers << 32 | ~global id); the
+ * maximum of the keys of all shares names the pose the sequential loop
+ * (query_processor_basic.cpp:214-225) keeps over the whole range.  result->best_hyp is global. */
+int pose_amd_ransac_range(pose_amd_ctx *ctx, int sample_mode, uint64_t seed, uint32_t query_id, uint32_t hyp_begin,
+                          uint32_t hyp_count, double eps, pose_amd_result *result, uint64_t *key);
+
 /* ---- measurement -------------------------------------------------------------------------- */
 /* Kernel time of the last pose_amd_ransac_run measured with HIP events on the context's
  * stream, summed over the call's chunks: ms[0] solve (all solver kernels), ms[1] score,

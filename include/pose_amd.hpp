@@ -333,6 +333,7 @@ class QueryProcessorBasic : public QueryProcessor {
 public:
     using QueryProcessor::QueryProcessor;
     uint32_t max_ransac_steps = 10000;
+    std::vector<int> devices;    // ProcessBatch: GPUs to spread the queries over (empty: this processor's device only)
     // query_processor_basic.cpp:105-293
     bool Process(Query &query, std::vector<SiftMatch> &good_matches, std::vector<feature_3D_info> &sifts) override
     {
@@ -383,9 +384,14 @@ public:
         prm.select_mode = select_mode; prm.eps = inlier_eps; prm.early_exit = 1;
         prm.inlier_divisor = inlier_divisor; prm.inlier_absolute = inlier_absolute;
         results.assign(nq, pose_amd_result{});
-        dev_->check(pose_amd_ransac_batch(dev_->ctx(), (int)nq, desc.data(), POSE_AMD_SAMPLE_BASIC, seed, max_ransac_steps, &prm,
-                                          results.data()),
-                    "ransac_batch");
+        if (devices.empty()) {
+            dev_->check(pose_amd_ransac_batch(dev_->ctx(), (int)nq, desc.data(), POSE_AMD_SAMPLE_BASIC, seed, max_ransac_steps, &prm,
+                                              results.data()),
+                        "ransac_batch");
+        } else if (pose_amd_ransac_batch_multi(devices.data(), (int)devices.size(), (int)nq, desc.data(), POSE_AMD_SAMPLE_BASIC, seed,
+                                               max_ransac_steps, &prm, results.data()) != POSE_AMD_OK) {
+            throw std::runtime_error(std::string("ransac_batch_multi: ") + pose_amd_multi_last_error());
+        }
         for (size_t i = 0; i < nq; ++i) {
             const pose_amd_result &r = results[i];
             Query &q = *queries[i];

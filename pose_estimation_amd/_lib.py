@@ -66,6 +66,12 @@ SIGNATURES = {
     "pose_amd_best_mask": (C.c_int, [_ctx, _u8]),
     "pose_amd_ransac_batch": (C.c_int, [_ctx, C.c_int, C.POINTER(QueryDesc), C.c_int, C.c_uint64, C.c_uint32, C.POINTER(Params),
                                         C.POINTER(Result)]),
+    "pose_amd_partition_queries": (C.c_int, [C.c_int, _ip, C.c_int, _ip]),
+    "pose_amd_ransac_batch_multi": (C.c_int, [_ip, C.c_int, C.c_int, C.POINTER(QueryDesc), C.c_int, C.c_uint64, C.c_uint32, C.POINTER(Params),
+                                              C.POINTER(Result)]),
+    "pose_amd_multi_last_error": (C.c_char_p, []),
+    "pose_amd_multi_release": (None, []),
+    "pose_amd_ransac_range": (C.c_int, [_ctx, C.c_int, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_double, C.POINTER(Result), _u64]),
     "pose_amd_last_timing": (C.c_int, [_ctx, C.POINTER(C.c_float)]),
 }
 

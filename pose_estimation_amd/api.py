@@ -249,6 +249,28 @@ class Context:
             return res
         return [result_dict(r) for r in res[:nq]]
 
+    def ransac_batch_multi(self, devices, queries, sample_mode=SAMPLE_BASIC, seed=0, budget=10000, select_mode=SELECT_COVERAGE, eps=0.5,
+                           early_exit=True, inlier_divisor=10, inlier_absolute=12):
+        """ransac_batch spread over the listed devices inside the library (one host thread and one
+        context per listed device, queries partitioned longest first).  Same results, same order."""
+        prep = queries if isinstance(queries, PreparedBatch) else self.prepare_batch(queries)
+        prm = Params(int(select_mode), float(eps), int(bool(early_exit)), int(inlier_divisor), int(inlier_absolute))
+        res = (Result * max(prep.nq, 1))()
+        dev = np.ascontiguousarray(devices, dtype=np.int32)
+        rc = self._lib.pose_amd_ransac_batch_multi(_ptr(dev, _lib._ip), len(dev), prep.nq, prep.descs, int(sample_mode), int(seed), int(budget),
+                                                   C.byref(prm), res)
+        if rc != 0:
+            raise PoseAmdError(f"ransac_batch_multi failed ({rc}): {self._lib.pose_amd_multi_last_error().decode()}")
+        return [result_dict(r) for r in res[:prep.nq]]
+
+    def ransac_range(self, sample_mode, seed, query_id, hyp_begin, hyp_count, eps=0.5):
+        """One share of a hypothesis-sharded query: (result dict with global best_hyp, packed key)."""
+        res = Result()
+        key = C.c_uint64(0)
+        self._chk(self._lib.pose_amd_ransac_range(self._h, int(sample_mode), int(seed), int(query_id), int(hyp_begin), int(hyp_count), float(eps),
+                                                  C.byref(res), C.byref(key)), "ransac_range")
+        return result_dict(res), key.value
+
     def best_mask(self):
         m = np.zeros(self.n, dtype=np.uint8)
         self._chk(self._lib.pose_amd_best_mask(self._h, _ptr(m, _lib._u8)), "best_mask")

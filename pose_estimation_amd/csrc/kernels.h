@@ -335,7 +335,10 @@ __device__ __forceinline__ void gather_p4pf(const query_dev &q, const uint4 s, d
 // consumer reads it coalesced) plus a status word.  Inputs come either from the resident query +
 // sample tuples or, for the batch entry point, from explicit m2d / M3D arrays.
 // ------------------------------------------------------------------------------------------
-constexpr int ELIM_BATCH = 32;     // systems per block and round at most; the launch passes a `batch` <= this that is a multiple of 4
+#ifndef POSE_AMD_ELIM_BATCH
+#define POSE_AMD_ELIM_BATCH 32
+#endif
+constexpr int ELIM_BATCH = POSE_AMD_ELIM_BATCH;     // systems per block and round at most; the launch passes a `batch` <= this that is a multiple of 4
                                    // (small launches use small batches so that they still fill the chip)
 constexpr int P4PF_TAIL = 75;      // doubles per hypothesis between the elimination and the finish kernel, stored [75][count]
 
@@ -850,15 +853,11 @@ __global__ __launch_bounds__(SCORE_THREADS) __attribute__((amdgpu_waves_per_eu(6
 // that the 2h extra rows of a band do not fit the LDS.
 // ------------------------------------------------------------------------------------------
 constexpr int COV_UNROLL = 8;
-__global__ __launch_bounds__(256) void k_coverage(query_dev q, int nposes, const double *__restrict__ proj, const int *__restrict__ slots,
-                                                  double eps, int all_matches, int band_rows, int words_per_row,
-                                                  unsigned long long *__restrict__ band_sums)
+// One (pose, band) of k_coverage by the whole block; every early return is taken by all threads.
+__device__ __forceinline__ void coverage_band(const query_dev &q, int pose, const double *__restrict__ proj, const int *__restrict__ slots,
+                                              double eps, int all_matches, int band_rows, int words_per_row,
+                                              unsigned long long *__restrict__ band_sums, unsigned int *s_bm, unsigned long long *s_sum, int &s_any)
 {
-    extern __shared__ unsigned int s_bm[];                   // nh painted rows, then ng rows of group unions
-    __shared__ unsigned long long s_sum[4];
-    __shared__ int s_any;
-    const int pose = blockIdx.x;
-    if (pose >= nposes) return;
     const int tid = threadIdx.x;
     unsigned long long *out = band_sums + (size_t)pose * gridDim.y + blockIdx.y;
     const int row0 = blockIdx.y * band_rows, row1 = min(q.height, row0 + band_rows);
@@ -964,14 +963,26 @@ __global__ __launch_bounds__(256) void k_coverage(query_dev q, int nposes, const
     if (tid == 0) *out = s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3];
 }
 
-__global__ __launch_bounds__(256) void k_coverage_direct(query_dev q, int nposes, const double *__restrict__ proj, const int *__restrict__ slots,
-                                                  double eps, int all_matches, int band_rows, int words_per_row,
+// nposes_dev, when given, holds the number of poses (a list built on the device); the blocks of
+// a launch share the poses round-robin, so the grid need not match their number.
+__global__ __launch_bounds__(256) void k_coverage(query_dev q, int nposes, const int *__restrict__ nposes_dev, const double *__restrict__ proj,
+                                                  const int *__restrict__ slots, double eps, int all_matches, int band_rows, int words_per_row,
                                                   unsigned long long *__restrict__ band_sums)
 {
-    extern __shared__ unsigned int s_bm[];
-    __shared__ unsigned long long s_sum[256];
-    const int pose = blockIdx.x;
-    if (pose >= nposes) return;
+    extern __shared__ unsigned int s_bm[];                   // nh painted rows, then ng rows of group unions
+    __shared__ unsigned long long s_sum[4];
+    __shared__ int s_any;
+    const int n = nposes_dev ? *nposes_dev : nposes;
+    for (int pose = blockIdx.x; pose < n; pose += gridDim.x) {
+        coverage_band(q, pose, proj, slots, eps, all_matches, band_rows, words_per_row, band_sums, s_bm, s_sum, s_any);
+        __syncthreads();
+    }
+}
+
+__device__ __forceinline__ void coverage_band_direct(const query_dev &q, int pose, const double *__restrict__ proj, const int *__restrict__ slots,
+                                                     double eps, int all_matches, int band_rows, int words_per_row,
+                                                     unsigned long long *__restrict__ band_sums, unsigned int *s_bm, unsigned long long *s_sum)
+{
     const int tid = threadIdx.x;
     const int row0 = blockIdx.y * band_rows, row1 = min(q.height, row0 + band_rows);
     const int nwords = (row1 - row0) * words_per_row;
@@ -1027,6 +1038,263 @@ __global__ __launch_bounds__(256) void k_coverage_direct(query_dev q, int nposes
     __syncthreads();
     for (int o = 128; o > 0; o >>= 1) { if (tid < o) s_sum[tid] += s_sum[tid + o]; __syncthreads(); }
     if (tid == 0) band_sums[(size_t)pose * gridDim.y + blockIdx.y] = s_sum[0];
+}
+
+__global__ __launch_bounds__(256) void k_coverage_direct(query_dev q, int nposes, const int *__restrict__ nposes_dev, const double *__restrict__ proj,
+                                                         const int *__restrict__ slots, double eps, int all_matches, int band_rows, int words_per_row,
+                                                         unsigned long long *__restrict__ band_sums)
+{
+    extern __shared__ unsigned int s_bm[];
+    __shared__ unsigned long long s_sum[256];
+    const int n = nposes_dev ? *nposes_dev : nposes;
+    for (int pose = blockIdx.x; pose < n; pose += gridDim.x) {
+        coverage_band_direct(q, pose, proj, slots, eps, all_matches, band_rows, words_per_row, band_sums, s_bm, s_sum);
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Coverage-quality selection of a chunk on the device (query_processor.cpp:171-174,
+// query_processor_basic.cpp:132-133, 214-225): the sequential loop keeps a pose iff its quality
+// A_f / A_g is strictly larger than that of every earlier pose, and stops after the first step
+// at whose end the kept pose has >= thresh inliers.  A_g is fixed for the query, so qualities
+// compare like the integer areas A_f, and A_f <= count * box (box = area of one coverage box)
+// tells which poses cannot win without painting them.  Three single-block kernels around two
+// k_coverage launches, no host round trip:
+//   k_cov_records    poses whose inlier count exceeds every earlier count ("count records"; a
+//                    handful) and whose bound beats the area carried in from earlier chunks
+//   k_cov_candidates with the records' areas as a lower bound of the running best area: every
+//                    other pose whose bound beats that lower bound at its position
+//   k_cov_final      ordered replay over records + candidates with their exact areas: the kept
+//                    pose, the step the loop ends at, the number of poses scored until then
+// state (unsigned long long words): [0] best area, [1] best count, [2] 1 if a pose has been kept,
+//   [3] steps used in the chunk, [4] poses scored in the chunk, [5] 1 if the loop ended inside
+//   the chunk, [6] slot of the pose kept in THIS chunk or ~0, [7] unused, [8..20] its pose record,
+//   [21..32] its projection matrix.  Words 0..2 carry over from chunk to chunk.
+// ------------------------------------------------------------------------------------------
+constexpr int COVSEL_THREADS = 256;
+
+constexpr int COVSEL_K = 8;          // consecutive slots per thread and tile of the ordered scans
+
+// Exclusive scan over the block's threads (thread order) of one value per thread; `total` gets
+// the reduction over all threads.  s_tmp: one entry per wave.  Two barriers.
+template <typename T, typename OP>
+__device__ __forceinline__ T covsel_block_scan(T v, T identity, OP op, T *s_tmp, T &total)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    T inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const T u = __shfl_up(inc, o); if (lane >= o) inc = op(inc, u); }
+    if (lane == 63) s_tmp[wave] = inc;
+    __syncthreads();
+    T before = identity;
+    total = identity;
+#pragma unroll
+    for (int w2 = 0; w2 < COVSEL_THREADS / 64; ++w2) { if (w2 < wave) before = op(before, s_tmp[w2]); total = op(total, s_tmp[w2]); }
+    const T up = __shfl_up(inc, 1);
+    __syncthreads();
+    return lane == 0 ? before : op(before, up);
+}
+
+struct covsel_max { template <typename T> __device__ T operator()(T a, T b) const { return a > b ? a : b; } };
+struct covsel_add { template <typename T> __device__ T operator()(T a, T b) const { return a + b; } };
+
+__global__ __launch_bounds__(COVSEL_THREADS) void k_cov_records(int nslots, const int *__restrict__ counts, const int *__restrict__ nsol, int maxsol,
+                                                                 long long box, const unsigned long long *__restrict__ state,
+                                                                 int *__restrict__ list1, int *__restrict__ n1)
+{
+    __shared__ int s_tmp[COVSEL_THREADS / 64];
+    const int tid = threadIdx.x;
+    const long long carried = (long long)state[0];
+    int run = 0;                                         // largest count of all earlier valid slots
+    int n = 0;
+    for (int base = 0; base < nslots; base += COVSEL_THREADS * COVSEL_K) {
+        int c[COVSEL_K], pre[COVSEL_K];
+        int lm = 0;
+#pragma unroll
+        for (int k = 0; k < COVSEL_K; ++k) {
+            const int s = base + tid * COVSEL_K + k;
+            const bool valid = s < nslots && (s % maxsol) < nsol[s / maxsol];
+            c[k] = valid ? counts[s] : 0;
+        }
+#pragma unroll
+        for (int k = 0; k < COVSEL_K; ++k) { pre[k] = lm; lm = max(lm, c[k]); }
+        int tilemax;
+        const int before = max(run, covsel_block_scan(lm, 0, covsel_max(), s_tmp, tilemax));
+        // a count record: more inliers than every earlier pose of the chunk (so c > 0), and a bound
+        // that beats the area carried in
+        unsigned flags = 0;
+        int mine = 0;
+#pragma unroll
+        for (int k = 0; k < COVSEL_K; ++k)
+            if (c[k] > max(before, pre[k]) && (long long)c[k] * box > carried) { flags |= 1u << k; ++mine; }
+        int total;
+        int off = n + covsel_block_scan(mine, 0, covsel_add(), s_tmp, total);
+#pragma unroll
+        for (int k = 0; k < COVSEL_K; ++k) if (flags & (1u << k)) list1[off++] = base + tid * COVSEL_K + k;
+        n += total;
+        run = max(run, tilemax);
+    }
+    if (tid == 0) *n1 = n;
+}
+
+// areas of a list entry = sum of its band sums
+__device__ __forceinline__ long long covsel_area(const unsigned long long *__restrict__ bands, int i, int nb)
+{
+    long long a = 0;
+    for (int b = 0; b < nb; ++b) a += (long long)bands[(size_t)i * nb + b];
+    return a;
+}
+
+__device__ __forceinline__ int covsel_lower_bound(const int *__restrict__ a, int n, int v)
+{
+    int lo = 0, hi = n;
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (a[mid] < v) lo = mid + 1; else hi = mid; }
+    return lo;
+}
+
+__global__ __launch_bounds__(COVSEL_THREADS) void k_cov_candidates(int nslots, const int *__restrict__ counts, const int *__restrict__ nsol, int maxsol,
+                                                                    long long box, const unsigned long long *__restrict__ state,
+                                                                    const int *__restrict__ list1, const int *__restrict__ n1p,
+                                                                    const unsigned long long *__restrict__ bands1, int nbands,
+                                                                    long long *__restrict__ area1, int *__restrict__ list2, int *__restrict__ n2)
+{
+    __shared__ int s_tmp[COVSEL_THREADS / 64];
+    const int tid = threadIdx.x;
+    const int n1 = *n1p;
+    const long long carried = (long long)state[0];
+    // exact areas of the records, then their running maximum in slot order (the list is in slot
+    // order and short -- counts rise strictly along it -- so one thread does the prefix pass)
+    for (int i = tid; i < n1; i += COVSEL_THREADS) area1[i] = covsel_area(bands1, i, nbands);
+    __syncthreads();
+    if (tid == 0) {
+        long long m = carried;
+        for (int i = 0; i < n1; ++i) { m = max(m, area1[i]); area1[n1 + i] = m; }      // area1[n1 + i]: best area after record i
+    }
+    __syncthreads();
+    int n = 0;
+    for (int base = 0; base < nslots; base += COVSEL_THREADS * COVSEL_K) {
+        unsigned flags = 0;
+        int mine = 0;
+        const int s0 = base + tid * COVSEL_K;
+        // records before the thread's first slot; the thread's own slots advance the position
+        int pos = covsel_lower_bound(list1, n1, s0);
+#pragma unroll
+        for (int k = 0; k < COVSEL_K; ++k) {
+            const int s = s0 + k;
+            if (s >= nslots) break;
+            const bool is_record = pos < n1 && list1[pos] == s;
+            if (!is_record && (s % maxsol) < nsol[s / maxsol]) {
+                const int c = counts[s];
+                const long long bound = pos > 0 ? area1[n1 + pos - 1] : carried;   // lower bound of the running best area before s
+                if (c > 0 && (long long)c * box > bound) { flags |= 1u << k; ++mine; }
+            }
+            if (is_record) ++pos;
+        }
+        int total;
+        int off = n + covsel_block_scan(mine, 0, covsel_add(), s_tmp, total);
+#pragma unroll
+        for (int k = 0; k < COVSEL_K; ++k) if (flags & (1u << k)) list2[off++] = s0 + k;
+        n += total;
+    }
+    if (tid == 0) *n2 = n;
+}
+
+// Replay in slot order over records + candidates, in parallel: (1) the two lists are merged by
+// rank (each is in slot order); (2) a pose is kept by the loop iff its area is strictly larger
+// than the carried area and every earlier area: an exclusive prefix maximum; (3) the loop ends
+// after the first step at whose end the kept pose -- the last keeper of that step -- has >= thresh
+// inliers; without such a step the last keeper of the chunk stays.
+// mslot / marea / mkeep: scratch for n1 + n2 entries.
+__global__ __launch_bounds__(COVSEL_THREADS) void k_cov_final(int nslots, int steps_in_chunk, const int *__restrict__ counts, const int *__restrict__ nsol,
+                                                               int maxsol, unsigned int thresh, int early_exit, const int *__restrict__ list1,
+                                                               const int *__restrict__ n1p, const long long *__restrict__ area1,
+                                                               const int *__restrict__ list2, const int *__restrict__ n2p,
+                                                               const unsigned long long *__restrict__ bands2, int nbands,
+                                                               int *__restrict__ mslot, long long *__restrict__ marea, unsigned char *__restrict__ mkeep,
+                                                               const double *__restrict__ pose, const double *__restrict__ proj,
+                                                               unsigned long long *__restrict__ state)
+{
+    __shared__ long long s_tilemax[COVSEL_THREADS / 64];
+    __shared__ int s_exit[COVSEL_THREADS / 64], s_last[COVSEL_THREADS / 64];
+    __shared__ unsigned long long s_cnt[COVSEL_THREADS / 64];
+    __shared__ int s_steps, s_kept;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n1 = *n1p, n2 = *n2p, N = n1 + n2;
+    const long long carried = (long long)state[0];
+    for (int i = tid; i < n1; i += COVSEL_THREADS) {
+        const int pos = i + covsel_lower_bound(list2, n2, list1[i]);
+        mslot[pos] = list1[i]; marea[pos] = area1[i];
+    }
+    for (int j = tid; j < n2; j += COVSEL_THREADS) {
+        const int pos = j + covsel_lower_bound(list1, n1, list2[j]);
+        mslot[pos] = list2[j]; marea[pos] = covsel_area(bands2, j, nbands);
+    }
+    __syncthreads();
+    long long run = carried;
+    for (int base = 0; base < N; base += COVSEL_THREADS) {
+        const int idx = base + tid;
+        const long long a = idx < N ? marea[idx] : -1;
+        long long pm = a;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const long long v = __shfl_up(pm, o); if (lane >= o) pm = max(pm, v); }
+        if (lane == 63) s_tilemax[wave] = pm;
+        __syncthreads();
+        long long before = run, tmax = run;
+#pragma unroll
+        for (int w2 = 0; w2 < COVSEL_THREADS / 64; ++w2) { if (w2 < wave) before = max(before, s_tilemax[w2]); tmax = max(tmax, s_tilemax[w2]); }
+        const long long up = __shfl_up(pm, 1);
+        const long long earlier = lane == 0 ? before : max(before, up);
+        if (idx < N) mkeep[idx] = a > earlier ? 1 : 0;
+        run = tmax;
+        __syncthreads();
+    }
+    int exit_idx = 0x7fffffff, last_idx = -1;
+    for (int idx = tid; idx < N; idx += COVSEL_THREADS) {
+        if (!mkeep[idx]) continue;
+        last_idx = max(last_idx, idx);
+        const int step = mslot[idx] / maxsol;
+        bool last_in_step = true;
+        for (int d = 1; d < maxsol && idx + d < N; ++d)
+            if (mslot[idx + d] / maxsol == step && mkeep[idx + d]) last_in_step = false;
+        if (early_exit && last_in_step && (unsigned int)counts[mslot[idx]] >= thresh) exit_idx = min(exit_idx, idx);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { exit_idx = min(exit_idx, __shfl_xor(exit_idx, o)); last_idx = max(last_idx, __shfl_xor(last_idx, o)); }
+    if (lane == 0) { s_exit[wave] = exit_idx; s_last[wave] = last_idx; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w2 = 1; w2 < COVSEL_THREADS / 64; ++w2) { exit_idx = min(exit_idx, s_exit[w2]); last_idx = max(last_idx, s_last[w2]); }
+        const bool done = exit_idx != 0x7fffffff;
+        const int kept = done ? exit_idx : last_idx;             // index in the merged list, -1: nothing kept in this chunk
+        int steps = steps_in_chunk;
+        if (kept >= 0) {
+            const int slot = mslot[kept];
+            state[0] = (unsigned long long)marea[kept]; state[1] = (unsigned long long)(unsigned int)counts[slot]; state[2] = 1ull;
+            state[6] = (unsigned long long)slot;
+            if (done) steps = slot / maxsol + 1;
+        } else {
+            state[6] = ~0ull;
+        }
+        state[3] = (unsigned long long)steps; state[5] = done ? 1ull : 0ull;
+        s_steps = steps; s_kept = kept >= 0 ? mslot[kept] : -1;
+    }
+    __syncthreads();
+    // poses scored by the loop: the valid slots of the steps it ran
+    const int lim = min(s_steps * maxsol, nslots);
+    unsigned long long nv = 0;
+    for (int s = tid; s < lim; s += COVSEL_THREADS) nv += (s % maxsol) < nsol[s / maxsol] ? 1ull : 0ull;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) nv += __shfl_xor(nv, o);
+    if (lane == 0) s_cnt[wave] = nv;
+    __syncthreads();
+    if (tid == 0) { unsigned long long t = 0; for (int w2 = 0; w2 < COVSEL_THREADS / 64; ++w2) t += s_cnt[w2]; state[4] = t; }
+    const int bs = s_kept;
+    if (bs >= 0) {
+        double *out = reinterpret_cast<double *>(state);
+        if (tid < 13) out[8 + tid] = pose[(size_t)bs * 13 + tid];
+        if (tid < 12) out[21 + tid] = proj[(size_t)bs * 12 + tid];
+    }
 }
 
 // ------------------------------------------------------------------------------------------

@@ -134,8 +134,12 @@ __device__ __forceinline__ int p3p_compute_poses(const double fa[3], const doubl
 }
 
 // Query::ComputeMatrices (query_loader.cpp:222-254): P = diag(f,f,1) [Rc^-1 | -Rc^-1 C].
+// Products and sums are kept as separate roundings: the matrix a pose gets must not depend on
+// which kernel the function was inlined into (the solver kernels store it for scoring, the
+// ComputeMatrices entry point recomputes it for the caller), and it is the reference's arithmetic.
 __device__ __forceinline__ void compute_matrices(double focal, const double C[3], const double Rc[9], double P[12])
 {
+#pragma clang fp contract(off)
     const double a = Rc[0], b = Rc[1], c = Rc[2], d = Rc[3], e = Rc[4], f = Rc[5], g = Rc[6], h = Rc[7], i = Rc[8];
     const double det = a * (e * i - f * h) - b * (d * i - f * g) + c * (d * h - e * g);
     const double inv[9] = {(e * i - f * h) / det, (c * h - b * i) / det, (b * f - c * e) / det,

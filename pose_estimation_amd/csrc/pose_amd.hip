@@ -77,7 +77,8 @@ struct pose_amd_ctx {
     size_t qstage_cap = 0;
     uint32_t cam_max = 0;          // largest camera id of the current camera sets
     pin_buf band_host;             // per-band coverage sums as downloaded
-    pin_buf h_nsol, h_counts, h_cand;   // coverage selection: per-chunk solution counts, inlier counts, candidate list
+    // coverage selection on the device: state words, record / candidate lists with their band sums, merge scratch
+    dev_buf cov_state, cov_n, cov_list1, cov_bands1, cov_area1, cov_list2, cov_bands2, cov_mslot, cov_marea, cov_mkeep;
     pin_buf h_words;               // small results: selection words + best pose (28 words), initial selection words, pose downloads
     int distinct_lindex = 0;       // distinct keypoint indices of the query, capped at 4 (the samplers need that many)
     bool sel_armed = false;        // sel[0..2] hold the initial values of a selection
@@ -252,8 +253,8 @@ int pose_amd_create(int device, pose_amd_ctx **out)
     if (hipMalloc(&c->gain.p, gain.size() * sizeof(double)) != hipSuccess) return bail("hipMalloc", hipErrorOutOfMemory);
     c->gain.cap = gain.size() * sizeof(double);
     if ((e = hipMemcpy(c->gain.p, gain.data(), c->gain.cap, hipMemcpyHostToDevice)) != hipSuccess) return bail("hipMemcpy", e);
-    if ((e = hipHostMalloc(&c->h_words.p, 64 * 8, hipHostMallocDefault)) != hipSuccess) return bail("hipHostMalloc", e);
-    c->h_words.cap = 64 * 8;
+    if ((e = hipHostMalloc(&c->h_words.p, 128 * 8, hipHostMallocDefault)) != hipSuccess) return bail("hipHostMalloc", e);
+    c->h_words.cap = 128 * 8;
     *out = c;
     return POSE_AMD_OK;
 }
@@ -265,10 +266,12 @@ void pose_amd_destroy(pose_amd_ctx *c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     dev_buf *bufs[] = {&c->qpack, &c->cam_off, &c->cam_ids, &c->gain, &c->samples,
                        &c->sample_status, &c->proj, &c->pose, &c->nsol, &c->counts, &c->sel, &c->bitmaps, &c->areas,
-                       &c->maskw, &c->arows, &c->pstatus, &c->projf, &c->feat, &c->vlist, &c->vcount, &c->arows2, &c->pstatus2, &c->vlist2, &c->vcount2, &c->in0, &c->in1, &c->in2, &c->out0, &c->out1, &c->out2, &c->out3};
+                       &c->maskw, &c->arows, &c->pstatus, &c->projf, &c->feat, &c->vlist, &c->vcount, &c->arows2, &c->pstatus2, &c->vlist2, &c->vcount2, &c->in0, &c->in1, &c->in2, &c->out0, &c->out1, &c->out2, &c->out3,
+                       &c->cov_state, &c->cov_n, &c->cov_list1, &c->cov_bands1, &c->cov_area1, &c->cov_list2, &c->cov_bands2, &c->cov_mslot, &c->cov_marea,
+                       &c->cov_mkeep};
     for (dev_buf *b : bufs) if (b->p) (void)hipFree(b->p);
     if (c->qstage) (void)hipHostFree(c->qstage);
-    pin_buf *pins[] = {&c->band_host, &c->h_nsol, &c->h_counts, &c->h_cand, &c->h_words};
+    pin_buf *pins[] = {&c->band_host, &c->h_words};
     for (pin_buf *b : pins) if (b->p) (void)hipHostFree(b->p);
     for (int i = 0; i < 6; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
     for (int i = 0; i < 6; ++i) if (c->ev2[i]) (void)hipEventDestroy(c->ev2[i]);
@@ -663,10 +666,10 @@ static int coverage_dev(pose_amd_ctx *ctx, int nposes, const double *proj_dev, d
         if (separable) {
             const int nh = band_rows + 2 * half - 1;
             const size_t lds = (size_t)(nh + (nh + 7) / 8) * wpr * 4;
-            hipLaunchKernelGGL(k_coverage, dim3(pt.cn, pt.bands), dim3(256), lds, ctx->stream, q, pt.cn, pd, sd, eps, all_matches,
+            hipLaunchKernelGGL(k_coverage, dim3(pt.cn, pt.bands), dim3(256), lds, ctx->stream, q, pt.cn, (const int *)nullptr, pd, sd, eps, all_matches,
                                band_rows, wpr, sums);
         } else {
-            hipLaunchKernelGGL(k_coverage_direct, dim3(pt.cn, pt.bands), dim3(256), (size_t)band_rows * wpr * 4, ctx->stream, q, pt.cn, pd, sd, eps,
+            hipLaunchKernelGGL(k_coverage_direct, dim3(pt.cn, pt.bands), dim3(256), (size_t)band_rows * wpr * 4, ctx->stream, q, pt.cn, (const int *)nullptr, pd, sd, eps,
                                all_matches, band_rows, wpr, sums);
         }
         HIPCHK(ctx, hipGetLastError());
@@ -702,6 +705,63 @@ int pose_amd_coverage_batch(pose_amd_ctx *ctx, int nposes, const double *P, doub
         if ((rc = upload(ctx, ctx->in1, dummy, 96))) return rc;
         if ((rc = coverage_dev(ctx, 1, (const double *)ctx->in1.p, eps, 1, area_all))) return rc;
     }
+    return POSE_AMD_OK;
+}
+
+// Coverage-quality selection of the chunk just scored (counts / nsol / proj / pose of `nslots` slots
+// = `steps` RANSAC steps), entirely on the device: count records -> their areas -> candidates ->
+// their areas -> ordered replay (kernels.h).  The running best (area, count) is carried in
+// cov_state[0..2] from chunk to chunk; one copy of the state words to page-locked memory ends it.
+// out[0..32]: state words as k_cov_final leaves them.
+static int coverage_select_chunk(pose_amd_ctx *ctx, const pose_amd_params *prm, int nslots, int steps, int maxsol, unsigned thresh, long long box,
+                                 unsigned long long *out)
+{
+    const query_dev q = make_query(ctx);
+    const int wpr = (ctx->width + 31) / 32;
+    if ((size_t)wpr * 4 > 48 * 1024) return fail(ctx, POSE_AMD_EINVAL, "coverage: image wider than 393216 px");
+    const int half = (int)std::ceil((float)ctx->width / 20.0f) / 2;
+    const int lds_rows = (64 * 1024) / (wpr * 4);
+    const int sep_rows = (lds_rows * 8) / 9 - 2 * half - 1;
+    const bool separable = sep_rows >= 8;
+    const int max_rows = separable ? std::min(ctx->height, sep_rows) : std::max(1, std::min(ctx->height, (48 * 1024) / (wpr * 4)));
+    // about sixteen bands per pose: the lists are short, the bands give the launch its blocks
+    const int band_rows = std::max(1, std::min(max_rows, cdiv(ctx->height, 16)));
+    const int bands = cdiv(ctx->height, band_rows);
+    const size_t n1cap = (size_t)std::min(nslots, ctx->n + 1);        // counts rise strictly along the records
+    int rc;
+    if ((rc = ensure(ctx, ctx->cov_n, 16)) || (rc = ensure(ctx, ctx->cov_list1, n1cap * 4)) || (rc = ensure(ctx, ctx->cov_bands1, n1cap * bands * 8)) ||
+        (rc = ensure(ctx, ctx->cov_area1, n1cap * 16)) || (rc = ensure(ctx, ctx->cov_list2, (size_t)nslots * 4)) ||
+        (rc = ensure(ctx, ctx->cov_bands2, (size_t)nslots * bands * 8)) || (rc = ensure(ctx, ctx->cov_mslot, (n1cap + nslots) * 4)) ||
+        (rc = ensure(ctx, ctx->cov_marea, (n1cap + nslots) * 8)) || (rc = ensure(ctx, ctx->cov_mkeep, n1cap + nslots)))
+        return rc;
+    unsigned long long *state = (unsigned long long *)ctx->cov_state.p;
+    int *nn = (int *)ctx->cov_n.p;
+    const int *counts = (const int *)ctx->counts.p, *nsol = (const int *)ctx->nsol.p;
+    const double *proj = (const double *)ctx->proj.p;
+    auto cover = [&](int blocks, const int *n_dev, const int *list, unsigned long long *sums) {
+        if (separable) {
+            const int nh = band_rows + 2 * half - 1;
+            const size_t lds = (size_t)(nh + (nh + 7) / 8) * wpr * 4;
+            hipLaunchKernelGGL(k_coverage, dim3(blocks, bands), dim3(256), lds, ctx->stream, q, 0, n_dev, proj, list, prm->eps, 0, band_rows, wpr, sums);
+        } else {
+            hipLaunchKernelGGL(k_coverage_direct, dim3(blocks, bands), dim3(256), (size_t)band_rows * wpr * 4, ctx->stream, q, 0, n_dev, proj, list, prm->eps,
+                               0, band_rows, wpr, sums);
+        }
+    };
+    hipLaunchKernelGGL(k_cov_records, dim3(1), dim3(COVSEL_THREADS), 0, ctx->stream, nslots, counts, nsol, maxsol, box, state, (int *)ctx->cov_list1.p, nn);
+    cover(32, nn, (const int *)ctx->cov_list1.p, (unsigned long long *)ctx->cov_bands1.p);
+    hipLaunchKernelGGL(k_cov_candidates, dim3(1), dim3(COVSEL_THREADS), 0, ctx->stream, nslots, counts, nsol, maxsol, box, state,
+                       (const int *)ctx->cov_list1.p, nn, (const unsigned long long *)ctx->cov_bands1.p, bands, (long long *)ctx->cov_area1.p,
+                       (int *)ctx->cov_list2.p, nn + 1);
+    cover(128, nn + 1, (const int *)ctx->cov_list2.p, (unsigned long long *)ctx->cov_bands2.p);
+    hipLaunchKernelGGL(k_cov_final, dim3(1), dim3(COVSEL_THREADS), 0, ctx->stream, nslots, steps, counts, nsol, maxsol, thresh, prm->early_exit ? 1 : 0,
+                       (const int *)ctx->cov_list1.p, nn, (const long long *)ctx->cov_area1.p, (const int *)ctx->cov_list2.p, nn + 1,
+                       (const unsigned long long *)ctx->cov_bands2.p, bands, (int *)ctx->cov_mslot.p, (long long *)ctx->cov_marea.p,
+                       (unsigned char *)ctx->cov_mkeep.p, (const double *)ctx->pose.p, proj, state);
+    HIPCHK(ctx, hipGetLastError());
+    unsigned long long *host = (unsigned long long *)ctx->h_words.p + 64;
+    if ((rc = download(ctx, host, state, 33 * 8)) || (rc = pose_amd_synchronize(ctx))) return rc;
+    memcpy(out, host, 33 * 8);
     return POSE_AMD_OK;
 }
 
@@ -920,6 +980,10 @@ int pose_amd_ransac_run(pose_amd_ctx *ctx, const pose_amd_params *prm, pose_amd_
         }
         area_all = ctx->area_all;
     }
+    if (coverage) {
+        if ((rc = ensure(ctx, ctx->cov_state, 33 * 8))) return rc;
+        HIPCHK(ctx, hipMemsetAsync(ctx->cov_state.p, 0, 33 * 8, ctx->stream));      // nothing kept yet, area 0
+    }
     const long long cover = (long long)std::ceil((float)ctx->width / 20.0f);
     const long long box = (long long)(2 * (cover / 2)) * (2 * (cover / 2));   // largest area one coverage box can add
 
@@ -929,7 +993,6 @@ int pose_amd_ransac_run(pose_amd_ctx *ctx, const pose_amd_params *prm, pose_amd_
     uint64_t poses_scored = 0;
     double best_pose[13];
     bool done = false;
-    std::vector<int64_t> areas;
 
     for (uint32_t h0 = 0, hc = 0; h0 < H && !done; h0 += hc) {
         if (prm->early_exit && best_count >= thresh_u) break;          // loop condition, basic.cpp:132-133
@@ -955,48 +1018,18 @@ int pose_amd_ransac_run(pose_amd_ctx *ctx, const pose_amd_params *prm, pose_amd_
             if (c > best_count) { best_count = c; chunk_best = (long long)(0xFFFFFFFFu - (uint32_t)(out[0] & 0xFFFFFFFFu)); have_gathered = true; }
         } else {
             // Coverage quality q = A_f / A_g (query_processor.cpp:171-174).  A_g is fixed for the
-            // query, so q1 > q2 <=> A_f1 > A_f2, and A_f <= count * box prunes poses that cannot win.
-            if ((rc = ensure_pinned(ctx, ctx->h_nsol, (size_t)hc * 4)) || (rc = ensure_pinned(ctx, ctx->h_counts, nslots * 4)) ||
-                (rc = ensure_pinned(ctx, ctx->h_cand, 4096 * 4)))
-                return rc;
-            const int *h_nsol = (const int *)ctx->h_nsol.p, *h_counts = (const int *)ctx->h_counts.p;
-            int *cand = (int *)ctx->h_cand.p;
-            if ((rc = download(ctx, ctx->h_nsol.p, ctx->nsol.p, (size_t)hc * 4)) ||
-                (rc = download(ctx, ctx->h_counts.p, ctx->counts.p, nslots * 4)) || (rc = pose_amd_synchronize(ctx)))
-                return rc;
-            // candidates are evaluated speculatively in batches; the first batch is small (it
-            // usually raises the pruning bound a lot), later ones grow so that a chunk full of
-            // candidates does not cost one host round trip per 256 poses
-            int BATCH = 256;
-            size_t s = 0;
-            while (!done && s < nslots) {
-                size_t ncand = 0;
-                areas.resize((size_t)BATCH);
-                size_t scan = s;
-                while (scan < nslots && (int)ncand < BATCH) {
-                    const uint32_t h = (uint32_t)(scan / maxsol), k = (uint32_t)(scan % maxsol);
-                    if ((int)k < h_nsol[h] && h_counts[scan] > 0 && (long long)h_counts[scan] * box > best_area) cand[ncand++] = (int)scan;
-                    ++scan;
-                }
-                if (ncand) {
-                    // coverage_dev synchronises before it returns, so the list may be rewritten afterwards
-                    if ((rc = upload(ctx, ctx->in0, cand, ncand * 4))) return rc;
-                    if ((rc = coverage_dev(ctx, (int)ncand, (const double *)ctx->proj.p, prm->eps, 0, areas.data(),
-                                           (const int *)ctx->in0.p)))
-                        return rc;
-                }
-                size_t ci = 0;
-                for (size_t t = s; t < scan; ++t) {                  // replay in order
-                    const uint32_t h = (uint32_t)(t / maxsol), k = (uint32_t)(t % maxsol);
-                    if (k == 0 && prm->early_exit && best_count >= thresh_u) { chunk_steps = h; done = true; break; }
-                    if ((int)k < h_nsol[h]) ++poses_scored;
-                    if (ci < ncand && (size_t)cand[ci] == t) {
-                        const int64_t a = areas[ci++];
-                        if (a > best_area) { best_area = a; best_count = (uint32_t)h_counts[t]; chunk_best = (long long)t; }
-                    }
-                }
-                s = scan;
-                BATCH = std::min(4096, BATCH * 4);
+            // query, so q1 > q2 <=> A_f1 > A_f2; pruning, painting and the ordered replay all run
+            // on the device (coverage_select_chunk), this side only reads the outcome.
+            unsigned long long w[33];
+            if ((rc = coverage_select_chunk(ctx, prm, (int)nslots, (int)hc, maxsol, thresh_u, box, w))) return rc;
+            chunk_steps = (uint32_t)w[3];
+            poses_scored += w[4];
+            done = w[5] != 0ull;
+            if (w[6] != ~0ull) {
+                best_area = (int64_t)w[0]; best_count = (uint32_t)w[1];
+                chunk_best = (long long)w[6];
+                memcpy(gathered, w + 8, 25 * 8);
+                have_gathered = true;
             }
         }
         if (ctx->timing) {
@@ -1104,6 +1137,108 @@ int pose_amd_ransac_batch(pose_amd_ctx *ctx, int nq, const pose_amd_query *queri
     worker(ctx->lanes[0]);
     for (std::thread &t : pool) t.join();
     return status.load();
+}
+
+// ---- several GPUs from one host process ------------------------------------------------------------
+// Longest-processing-time-first assignment of queries to parts: queries in order of descending
+// cost (ties: lower index first), each to the part with the smallest load so far (ties: lower
+// part).  Deterministic; the same rule a multi-process launch uses to shard queries over ranks.
+int pose_amd_partition_queries(int nq, const int *costs, int nparts, int *part_of)
+{
+    if (nq < 0 || nparts <= 0 || (nq && (!costs || !part_of))) return POSE_AMD_EINVAL;
+    std::vector<int> order((size_t)nq);
+    for (int i = 0; i < nq; ++i) order[(size_t)i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return costs[a] > costs[b]; });
+    std::vector<long long> load((size_t)nparts, 0);
+    for (int q : order) {
+        int r = 0;
+        for (int p = 1; p < nparts; ++p) if (load[(size_t)p] < load[(size_t)r]) r = p;
+        part_of[q] = r;
+        load[(size_t)r] += costs[q];
+    }
+    return POSE_AMD_OK;
+}
+
+namespace {
+std::mutex g_multi_lock;
+std::vector<std::pair<int, pose_amd_ctx *>> g_multi_ctx;     // entry i: context of the i-th listed device of the last calls
+std::string g_multi_error;
+}
+
+const char *pose_amd_multi_last_error(void) { return g_multi_error.c_str(); }
+
+void pose_amd_multi_release(void)
+{
+    std::lock_guard<std::mutex> g(g_multi_lock);
+    for (auto &e : g_multi_ctx) pose_amd_destroy(e.second);
+    g_multi_ctx.clear();
+}
+
+int pose_amd_ransac_batch_multi(const int *devices, int ndev, int nq, const pose_amd_query *queries, int sample_mode, uint64_t seed,
+                                uint32_t budget, const pose_amd_params *prm, pose_amd_result *results)
+{
+    std::lock_guard<std::mutex> g(g_multi_lock);
+    if (!devices || ndev <= 0 || nq < 0 || (nq && (!queries || !results)) || !prm) { g_multi_error = "ransac_batch_multi: bad argument"; return POSE_AMD_EINVAL; }
+    if (nq == 0) return POSE_AMD_OK;
+    // one context per listed device (a device may be listed more than once), kept for later calls
+    for (int i = 0; i < ndev; ++i) {
+        if ((size_t)i < g_multi_ctx.size() && g_multi_ctx[(size_t)i].first == devices[i]) continue;
+        if ((size_t)i < g_multi_ctx.size()) { pose_amd_destroy(g_multi_ctx[(size_t)i].second); g_multi_ctx[(size_t)i] = {devices[i], nullptr}; }
+        else g_multi_ctx.push_back({devices[i], nullptr});
+        pose_amd_ctx *c = nullptr;
+        const int rc = pose_amd_create(devices[i], &c);
+        if (rc) { g_multi_error = "ransac_batch_multi: device " + std::to_string(devices[i]) + ": " + pose_amd_last_error(nullptr); g_multi_ctx.resize((size_t)i); return rc; }
+        g_multi_ctx[(size_t)i].second = c;
+    }
+    std::vector<int> costs((size_t)nq), part((size_t)nq);
+    for (int i = 0; i < nq; ++i) costs[(size_t)i] = queries[i].n;
+    pose_amd_partition_queries(nq, costs.data(), ndev, part.data());
+    std::vector<std::vector<int>> mine((size_t)ndev);
+    for (int i = 0; i < nq; ++i) mine[(size_t)part[(size_t)i]].push_back(i);
+    std::vector<int> status((size_t)ndev, POSE_AMD_OK);
+    // one host thread per device; each runs the single-device batch on its share (its worker
+    // threads and streams are that context's own), no exchange between devices
+    auto run = [&](int d) {
+        const std::vector<int> &idx = mine[(size_t)d];
+        std::vector<pose_amd_query> qs(idx.size());
+        std::vector<pose_amd_result> rs(idx.size());
+        for (size_t k = 0; k < idx.size(); ++k) qs[k] = queries[idx[k]];
+        pose_amd_ctx *c = g_multi_ctx[(size_t)d].second;
+        status[(size_t)d] = pose_amd_ransac_batch(c, (int)idx.size(), qs.data(), sample_mode, seed, budget, prm, rs.data());
+        for (size_t k = 0; k < idx.size(); ++k) results[idx[k]] = rs[k];
+    };
+    std::vector<std::thread> pool;
+    for (int d = 1; d < ndev; ++d) pool.emplace_back(run, d);
+    run(0);
+    for (std::thread &t : pool) t.join();
+    for (int d = 0; d < ndev; ++d)
+        if (status[(size_t)d]) {
+            g_multi_error = "ransac_batch_multi: device " + std::to_string(devices[d]) + ": " + pose_amd_last_error(g_multi_ctx[(size_t)d].second);
+            return status[(size_t)d];
+        }
+    return POSE_AMD_OK;
+}
+
+// One rank's share of a hypothesis-sharded query: draws and evaluates the ids [hyp_begin,
+// hyp_begin + hyp_count) of the query's counter-based stream (inlier-count selection, no early
+// exit) and packs (inlier count, global hypothesis id) so that the maximum over all shares is the
+// pose the sequential loop over the whole range keeps: more inliers first, then the lower id.
+int pose_amd_ransac_range(pose_amd_ctx *ctx, int sample_mode, uint64_t seed, uint32_t query_id, uint32_t hyp_begin, uint32_t hyp_count,
+                          double eps, pose_amd_result *result, uint64_t *key)
+{
+    if (!ctx || !result || !key) return fail(ctx, POSE_AMD_EINVAL, "ransac_range: bad argument");
+    *key = 0;
+    int rc = pose_amd_sample(ctx, sample_mode, seed, query_id, hyp_begin, hyp_count, nullptr);
+    if (rc) return rc;
+    pose_amd_params prm;
+    memset(&prm, 0, sizeof prm);
+    prm.select_mode = POSE_AMD_SELECT_INLIERS; prm.eps = eps; prm.early_exit = 0; prm.inlier_divisor = 10; prm.inlier_absolute = 12;
+    if ((rc = pose_amd_ransac_run(ctx, &prm, result, nullptr, nullptr))) return rc;
+    if (result->found) {
+        result->best_hyp += hyp_begin;                       // global id
+        *key = ((uint64_t)result->inliers << 32) | (uint64_t)(0xFFFFFFFFu - result->best_hyp);
+    }
+    return POSE_AMD_OK;
 }
 
 int pose_amd_best_mask(pose_amd_ctx *ctx, uint8_t *mask)

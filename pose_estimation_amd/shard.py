@@ -26,7 +26,8 @@ def hypothesis_shard(total, rank, world):
 
 def query_shard(costs, rank, world):
     """Indices of the queries `rank` processes.  `costs` (one number per query, e.g. its match
-    count) balances the load: longest-processing-time-first assignment, deterministic."""
+    count) balances the load: longest-processing-time-first assignment, deterministic (the rule of
+    pose_amd_partition_queries, which spreads a batch over the devices of one process)."""
     costs = np.asarray(costs, dtype=np.float64)
     order = np.argsort(-costs, kind="stable")
     load = np.zeros(world)

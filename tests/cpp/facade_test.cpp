@@ -183,6 +183,28 @@ static void test_batch()
         CHECK(a(0, 0) == b(0, 0) && a(1, 0) == b(1, 0) && a(2, 0) == b(2, 0));
         CHECK(scenes[i].query.focal_length() == single.query.focal_length());
     }
+    // the same batch spread over a device list (device 0 twice: two contexts, two host threads)
+    std::vector<Scene> again;
+    for (int i = 0; i < 6; ++i) again.push_back(make_scene(500 + 40 * i, 150 + 20 * i, (i & 1) != 0, 20u + i));
+    std::vector<Query *> q2;
+    std::vector<std::vector<SiftMatch> *> m2;
+    unsigned base = 0;
+    for (Scene &s : again) {
+        for (SiftMatch &m : s.matches) m.mindex += base;
+        base += (unsigned)s.sifts.size();
+        q2.push_back(&s.query);
+        m2.push_back(&s.matches);
+    }
+    QueryProcessorBasic multi;
+    multi.seed = 77; multi.query_id = 5;
+    multi.devices = {0, 0};
+    std::vector<pose_amd_result> r2;
+    CHECK(multi.ProcessBatch(q2, m2, sifts, r2));
+    for (size_t i = 0; i < scenes.size(); ++i) {
+        CHECK(r2[i].found == results[i].found && r2[i].steps == results[i].steps && r2[i].best_hyp == results[i].best_hyp && r2[i].inliers == results[i].inliers);
+        CHECK(again[i].query.camera_position()(0, 0) == scenes[i].query.camera_position()(0, 0));
+    }
+    pose_amd_multi_release();
 }
 
 // SoA view of a scene's matches for the oracle

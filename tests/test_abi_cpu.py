@@ -43,3 +43,25 @@ def test_no_gpu_means_error_not_fallback():
     from pose_estimation_amd import Context, PoseAmdError
     with pytest.raises(PoseAmdError):
         Context(0)
+
+
+def test_query_partition_is_the_sharding_rule():
+    """pose_amd_partition_queries (host code, spreads a batch over the devices of one process) assigns
+    exactly as shard.query_shard assigns queries to ranks; loads are balanced."""
+    import numpy as np
+    from pose_estimation_amd import shard
+    lib = _lib.load()
+    rng = np.random.default_rng(4)
+    for nq, parts in ((0, 3), (1, 4), (50, 2), (800, 8), (37, 5)):
+        costs = np.ascontiguousarray(rng.integers(4000, 6001, nq), dtype=np.int32)
+        if nq > 10:
+            costs[::7] = costs[0]                                   # equal costs: ties go to the lower index / lower part
+        part = np.full(max(nq, 1), -1, dtype=np.int32)
+        rc = lib.pose_amd_partition_queries(nq, costs.ctypes.data_as(_lib._ip), parts, part.ctypes.data_as(_lib._ip))
+        assert rc == 0
+        for r in range(parts):
+            assert [int(i) for i in np.nonzero(part[:nq] == r)[0]] == shard.query_shard(costs, r, parts)
+        if nq >= 50:
+            loads = [int(costs[part[:nq] == r].sum()) for r in range(parts)]
+            assert max(loads) - min(loads) <= costs.max()
+    assert lib.pose_amd_partition_queries(3, None, 2, None) != 0 and lib.pose_amd_partition_queries(3, None, 0, None) != 0

@@ -238,3 +238,60 @@ def test_eigen_step_root_sets_on_benchmark_stream(ctx, record_property):
         record_property(k, v)
     assert stable.mean() > 0.97
     assert rates["on_stable_tuples"] < 0.01, rates
+
+
+# ---- several devices / ranks through the C ABI -----------------------------------------------------------
+def test_batch_over_a_device_list_equals_the_single_device_batch(ctx):
+    """pose_amd_ransac_batch_multi with device 0 listed twice (two contexts, two host threads, the
+    queries partitioned longest first) returns what pose_amd_ransac_batch returns, in query order."""
+    queries = []
+    for i, (n, frac, known) in enumerate([(900, 0.3, False), (700, 0.5, True), (1500, 0.12, False), (64, 0.9, True), (9, 1.0, False),
+                                          (1200, 0.2, True), (800, 0.35, False), (500, 0.4, True), (1100, 0.15, False)]):
+        q = synth.make_query(n, frac, 500 + i, known_focal=known)
+        q["query_id"] = 7 + i
+        queries.append(q)
+    for select, early in ((SELECT_COVERAGE, True), (SELECT_INLIERS, False)):
+        one = ctx.ransac_batch(queries, SAMPLE_BASIC, seed=12, budget=500, select_mode=select, early_exit=early)
+        for devices in ([0, 0], [0, 0, 0], [0]):
+            many = ctx.ransac_batch_multi(devices, queries, SAMPLE_BASIC, seed=12, budget=500, select_mode=select, early_exit=early)
+            for a, b in zip(one, many):
+                for k in ("found", "inliers", "steps", "best_hyp", "best_sol", "poses_scored", "area_fit", "area_all"):
+                    assert a[k] == b[k], k
+                assert np.array_equal(a["C"], b["C"]) and np.array_equal(a["Rc"], b["Rc"]) and a["focal"] == b["focal"]
+    ctx._lib.pose_amd_multi_release()
+    with pytest.raises(Exception):
+        ctx.ransac_batch_multi([99], queries, SAMPLE_BASIC, seed=12, budget=10)
+
+
+def test_hypothesis_range_shares_reduce_to_the_whole_range(ctx):
+    """pose_amd_ransac_range: the maximum of the packed keys of three shares names the pose the
+    whole range keeps (and the oracle's sequential loop over the exported tuples)."""
+    from pose_estimation_amd import shard
+    q = synth.make_query(3000, 0.05, 77)
+    ctx.set_query(*oracle_args(q))
+    total = 600
+    whole, key_whole = ctx.ransac_range(SAMPLE_BASIC, 31, 4, 0, total)
+    keys = []
+    for r in range(3):
+        b, e = shard.hypothesis_shard(total, r, 3)
+        res, key = ctx.ransac_range(SAMPLE_BASIC, 31, 4, b, e - b)
+        assert b <= res["best_hyp"] < e and key == shard.pack_key(res["inliers"], res["best_hyp"])
+        keys.append(key)
+    assert max(keys) == key_whole and shard.unpack_key(max(keys)) == (whole["inliers"], whole["best_hyp"])
+    samples = ctx.sample(SAMPLE_BASIC, 31, 4, 0, total)
+    o = O.ransac(*oracle_args(q), samples, select_coverage=False, early_exit=False, max_steps=total)
+    assert (whole["inliers"], whole["best_hyp"]) == (o["hyposet"], o["best_step"])
+
+
+def test_two_rank_rehearsal_runs_the_hip_path_on_every_rank():
+    """bench.py --gpus 2 started plainly: it launches its two ranks itself (gloo process group, both
+    ranks on this GPU), every rank runs the HIP path on its hypothesis range and the packed keys are
+    max-all-reduced; rank 0's line reports both ranks' work."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "2", "--warmup", "1",
+                        "--hyps", "65536", "--no-cpu-baseline"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=280)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    line = json.loads(r.stdout.decode().strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["value"] > 0 and line["config"]["best_inliers"] >= 12

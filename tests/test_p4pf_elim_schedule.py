@@ -64,6 +64,32 @@ def test_schedule_reproduces_action_matrix_rows():
     assert np.median(errs) < 1e-10 and np.quantile(errs, 0.9) < 1e-8 and np.max(errs) < 1e-4, (np.median(errs), np.max(errs))
 
 
+def test_blocked_stage2_equals_step_by_step_elimination():
+    """The kernel takes the stage-2 pivots four at a time: panel steps on the block's own columns,
+    raw trailing rows of the pivots, effective multipliers m' = m L^-1, one update per block.
+    Same pivots, same result as publishing every pivot row at once (up to rounding that scales
+    with the conditioning of the sample); blocks cover every non-leading step exactly once and
+    no published row exceeds its LDS slot."""
+    s = G.build_schedule()
+    lead, blocks = G.stage2_blocks(s, G.BLOCK)
+    assert sorted(lead + [i for b in blocks for i in b["steps"]]) == list(range(24))
+    for b in blocks:
+        assert not (set(b["cols"]) & set(b["trail"])) and set(G.KEEP + G.RHS) <= set(b["trail"])
+        assert (len(b["trail"]) + len(b["cols"])) * 8 <= G.ROW_BYTES
+    m, M = synth.random_p4pf_problems(120, seed=19, contaminate=(0, 1, 2), noise=0.3)
+    errs = []
+    for i in range(120):
+        n, k, A, _ = O.p4pf_stages(m[i], M[i])
+        if n < 0:
+            continue
+        st1, A1 = G.simulate(s, k)
+        st2, A2 = G.simulate_blocked(s, k, G.BLOCK)
+        assert st1 == 0 and st2 == 0
+        errs.append(np.max(np.abs(A1 - A2)) / np.max(np.abs(A1)))
+    errs = np.array(errs)
+    assert len(errs) >= 110 and np.median(errs) < 1e-11 and np.quantile(errs, 0.9) < 1e-9 and np.max(errs) < 1e-5, (np.median(errs), np.max(errs))
+
+
 def test_generated_header_is_current():
     """The committed header equals what the generator emits for the default settings."""
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

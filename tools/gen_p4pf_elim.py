@@ -37,6 +37,8 @@ QUAD_BCAST = os.environ.get("P4PF_ELIM_QUAD_BCAST", "lds")   # pivot-row broadca
 SKIP = os.environ.get("P4PF_ELIM_SKIP", "")    # timing experiments only: "stage1" or "stage2" leaves that stage out
 PREFETCH = int(os.environ.get("P4PF_ELIM_PREFETCH", "0"))     # stage-1 steps between an LDS read and its first use (0..8 measured the same)
 ROW_BYTES = 320          # LDS bytes per published pivot row of a block (40 doubles); 320 mod 256 = 64 keeps the rows of a block on different banks
+TWO_ROUNDS = int(os.environ.get("P4PF_ELIM_TWO_ROUNDS", "0"))   # publish slot-0 pivots and slot-1 pivots in two rounds of stores without selects
+SPEC_RCP = int(os.environ.get("P4PF_ELIM_SPEC_RCP", "0"))   # every lane inverts its own candidates while the pivot search runs; the pivot lane's reciprocal is broadcast
 BLOCK = int(os.environ.get("P4PF_ELIM_BLOCK", "4"))      # stage-2 steps per block of delayed updates (0: one pivot row published per step)
 QUAD_CHUNK = int(os.environ.get("P4PF_ELIM_QUAD_CHUNK", "16"))   # pivot-row entries in flight per group of broadcasts
 
@@ -526,21 +528,31 @@ def emit(sched):
             need(c, 1)
         npadL = 0 if nb == 1 else 2 * ((nb - 1 + 1) // 2)          # doubles reserved for the L entries at the head of a row
         w(f"    {{ // stage 2 block {bi}: columns {cols}, {len(trail)} trailing columns")
-        w("        int pk = -1, pk2 = -1;            // this lane's first / second pivot inside the block")
-        w("        bool psl = false;                 // slot of the first one")
+        if TWO_ROUNDS:
+            w("        int pk0 = -1, pk1 = -1;           // index inside the block at which this lane's slot-0 / slot-1 row became the pivot")
+        else:
+            w("        int pk = -1, pk2 = -1;            // this lane's first / second pivot inside the block")
+            w("        bool psl = false;                 // slot of the first one")
         for k, c in enumerate(cols):
             w(f"        // step {blk['steps'][k]}: column {c}")
             w(f"        bool sl{k}, none{k};")
             w(f"        const int L{k} = row16_argmax_abs(r{c}_0, act0, r{c}_1, act1, sl{k}, none{k});")
             w(f"        bad |= none{k};")
-            w(f"        const double nr{k} = neg_rcp(lane_bcast(sl{k} ? r{c}_1 : r{c}_0, L{k}));")
+            if SPEC_RCP:
+                w(f"        const double q{k}_0 = neg_rcp(r{c}_0), q{k}_1 = neg_rcp(r{c}_1);")
+                w(f"        const double nr{k} = lane_bcast(sl{k} ? q{k}_1 : q{k}_0, L{k});")
+            else:
+                w(f"        const double nr{k} = neg_rcp(lane_bcast(sl{k} ? r{c}_1 : r{c}_0, L{k}));")
             # retired rows are never read again: no masking of their multipliers
             w(f"        double m{k}_0 = r{c}_0 * nr{k}, m{k}_1 = r{c}_1 * nr{k};")
             for c2 in cols[k + 1:]:
                 w(f"        {{ const double e = lane_bcast(sl{k} ? r{c2}_1 : r{c2}_0, L{k});")
                 w(f"          r{c2}_0 = fma(m{k}_0, e, r{c2}_0); r{c2}_1 = fma(m{k}_1, e, r{c2}_1); }}")
             w(f"        {{ const bool me = lane == L{k};")
-            w(f"          pk2 = me && pk >= 0 ? {k} : pk2; psl = me && pk < 0 ? sl{k} : psl; pk = me && pk < 0 ? {k} : pk;")
+            if TWO_ROUNDS:
+                w(f"          pk0 = me && !sl{k} ? {k} : pk0; pk1 = me && sl{k} ? {k} : pk1;")
+            else:
+                w(f"          pk2 = me && pk >= 0 ? {k} : pk2; psl = me && pk < 0 ? sl{k} : psl; pk = me && pk < 0 ? {k} : pk;")
             w(f"          act0 = act0 && !(me && !sl{k}); act1 = act1 && !(me && sl{k}); }}")
         # ---- publish: one masked round of stores for every lane's first pivot of the block
         items = []                                  # doubles of a row, in order: L entries, padding, trailing entries
@@ -557,6 +569,8 @@ def emit(sched):
 
         def val(it, other):
             kind, x = it
+            if TWO_ROUNDS:
+                return "0.0" if kind == "z" else f"{'mr'[kind == 'r']}{x}_{int(other)}"
             a, b = ("0", "1") if other else ("1", "0")
             if kind == "z":
                 return "0.0"
@@ -579,12 +593,16 @@ def emit(sched):
                 ops = ", ".join(f'[a{j - g0}] "v"({tag}{j})' for j in grp)
                 w(f'                     :: [mask] "s"(wm{tag}), [addr] "v"(addr{tag}), {ops} : "memory");')
 
-        round_of_stores("pa", False, "pk")
-        # a lane whose two rows both became pivots inside this block publishes the second one in a
-        # round of its own; taken only when some lane of the wave needs it
-        w("        if (__builtin_amdgcn_ballot_w64(pk2 >= 0) != 0ull) {")
-        round_of_stores("pb", True, "pk2")
-        w("        }")
+        if TWO_ROUNDS:
+            round_of_stores("pa", False, "pk0")
+            round_of_stores("pb", True, "pk1")
+        else:
+            round_of_stores("pa", False, "pk")
+            # a lane whose two rows both became pivots inside this block publishes the second one in a
+            # round of its own; taken only when some lane of the wave needs it
+            w("        if (__builtin_amdgcn_ballot_w64(pk2 >= 0) != 0ull) {")
+            round_of_stores("pb", True, "pk2")
+            w("        }")
         w("        __builtin_amdgcn_wave_barrier();")
         # ---- effective multipliers m' = m L^-1 (back substitution), L from the pivot rows' heads
         if nb > 1:
