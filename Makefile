@@ -13,11 +13,11 @@ IO_TEST := tests/cpp/io_test
 all: $(LIB) oracle $(SHIM) $(FACADE_TEST) $(IO_TEST)
 
 $(LIB): $(CSRC)/pose_amd.hip $(HDRS)
-	$(HIPCC) -O3 -std=c++17 --offload-arch=$(ARCH) -fPIC -shared -pthread -Wall -Wno-unused-function -o $@ $<
+	$(HIPCC) -O3 -std=c++17 --offload-arch=$(ARCH) -ffp-contract=on -fPIC -shared -pthread -Wall -Wno-unused-function -o $@ $<
 
 # Host build of the per-lane eigen step, used only by the CPU tests.
 $(SHIM): tests/host_shim/eig_shim.hip $(HDRS)
-	$(HIPCC) -O2 -std=c++17 --offload-arch=$(ARCH) -fPIC -shared -Wno-unused-function -o $@ $<
+	$(HIPCC) -O2 -std=c++17 --offload-arch=$(ARCH) -ffp-contract=on -fPIC -shared -Wno-unused-function -o $@ $<
 
 # Test drivers of the C++ host facade (plain g++, link the library through its C ABI; the GPU
 # one also links the CPU oracle, as its checker).

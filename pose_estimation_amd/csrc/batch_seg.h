@@ -1,0 +1,202 @@
+// Many queries in one launch sequence ("segmented" launches) for the multi-query entry point.
+//
+// The per-query kernels of kernels.h take one query by value.  A batch of a few hundred
+// queries with a thousand RANSAC steps each gives every such launch a few dozen waves -- far
+// too few for 256 compute units, so their time is launch and dependency latency.  The kernels
+// here run the same device code for a whole group of queries at once: blockIdx.y (or .z) picks
+// the query from a descriptor table, and each query owns a segment of `S` steps in every
+// per-hypothesis array (hypothesis index = position in the group * S + step, pose slot = that
+// * maxsol + solution).  Results are identical to the per-query launches.
+#pragma once
+#include "kernels.h"
+
+namespace pose_amd {
+
+struct seg_query {
+    query_dev q;                 // pointers into the batch's packed correspondence arrays
+    uint32_t query_id;           // selects the random stream (pose_amd_sample)
+    int maxsol;                  // 4 (P3P) or 10 (P4Pf)
+    unsigned thresh;             // early-exit threshold min(n / inlier_divisor, inlier_absolute)
+    long long box;               // area of one coverage box
+    int band_rows, bands, wpr;   // coverage geometry of the query's image
+    int separable;               // the row-union coverage kernel fits this image
+    int bm_words;                // advanced sampler: words of the camera bitmap, 0 = merge lists
+};
+
+// what a launch needs to find its query and its segment
+struct seg_launch {
+    const seg_query *qt;
+    const int *active;           // query indices of the group, one per blockIdx.y / .z
+    int S;                       // segment length: steps a query has room for in every per-hypothesis array
+    int V;                       // steps of the round (<= S)
+    uint32_t step0;              // first step of the round
+};
+
+__device__ __forceinline__ const seg_query &seg_of(const seg_launch &L, int a) { return L.qt[L.active[a]]; }
+
+__global__ void k_seg_sample_basic(seg_launch L, uint64_t seed, uint32_t *__restrict__ samples)
+{
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= (uint32_t)L.V) return;
+    const seg_query &sq = seg_of(L, blockIdx.y);
+    sample_basic_one(sq.q, sq.maxsol == P4PF_MAXSOL ? 4 : 3, seed, sq.query_id, L.step0 + j, samples, (size_t)blockIdx.y * L.S + j);
+}
+
+// one tuple per wave; dynamic LDS: SAMPLE_ADV_WAVES * max bm_words words
+__global__ __launch_bounds__(64 * SAMPLE_ADV_WAVES) void k_seg_sample_advanced(seg_launch L, uint64_t seed, const double *__restrict__ gain,
+                                                                                uint32_t *__restrict__ samples, int *__restrict__ status, int bm_stride)
+{
+    __shared__ uint32_t s_inter[SAMPLE_ADV_WAVES][MAXCAM];
+    extern __shared__ uint32_t s_cam_bits[];
+    const int wave = threadIdx.x >> 6;
+    const uint32_t j = blockIdx.x * SAMPLE_ADV_WAVES + wave;
+    if (j >= (uint32_t)L.V) return;                      // whole waves leave together
+    const seg_query &sq = seg_of(L, blockIdx.y);
+    const int m = sq.maxsol == P4PF_MAXSOL ? 4 : 3;
+    const size_t t = (size_t)blockIdx.y * L.S + j;
+    if (sq.bm_words)
+        sample_advanced_wave<true>(sq.q, m, seed, sq.query_id, L.step0 + j, t, gain, samples, status, sq.bm_words, s_inter[wave], s_cam_bits + wave * bm_stride);
+    else
+        sample_advanced_wave<false>(sq.q, m, seed, sq.query_id, L.step0 + j, t, gain, samples, status, 0, s_inter[wave], s_cam_bits);
+}
+
+__global__ __launch_bounds__(64) void k_seg_solve_p3p(seg_launch L, const uint32_t *__restrict__ samples, double *__restrict__ proj, double *__restrict__ pose,
+                                                      int *__restrict__ nsol, float *__restrict__ projf, double eps)
+{
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= (uint32_t)L.V) return;
+    solve_p3p_one(seg_of(L, blockIdx.y).q, (size_t)blockIdx.y * L.S + j, samples, proj, pose, nsol, projf, eps);
+}
+
+// tail systems: [75][total hypotheses of the group], total = gridDim.y * S
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_seg_p4pf_elim(seg_launch L, const uint32_t *__restrict__ samples,
+                                                                                                 double *__restrict__ Arows, int *__restrict__ status, int batch)
+{
+    const size_t base = (size_t)blockIdx.y * L.S;
+    p4pf_elim_block(seg_of(L, blockIdx.y).q, (uint32_t)L.V, samples + base * 4, nullptr, nullptr, Arows + base, (size_t)gridDim.y * L.S, status + base, batch,
+                    blockIdx.x, gridDim.x);
+}
+
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_seg_p4pf_finish(seg_launch L, const uint32_t *__restrict__ samples,
+                                                                                                   const double *__restrict__ Arows, const int *__restrict__ status,
+                                                                                                   double *__restrict__ proj, double *__restrict__ pose,
+                                                                                                   int *__restrict__ nsol, float *__restrict__ projf, double eps)
+{
+    const size_t base = (size_t)blockIdx.y * L.S, sbase = base * P4PF_MAXSOL;
+    p4pf_finish_block(seg_of(L, blockIdx.y).q, (uint32_t)L.V, samples + base * 4, nullptr, nullptr, Arows + base, (size_t)gridDim.y * L.S, status + base,
+                      proj + sbase * 12, pose + sbase * 13, nsol + base, nullptr, nullptr, nullptr, projf + sbase * 32, eps, blockIdx.x);
+}
+
+// packed-float32 screen + float64 decision, spb <= SCORE_SPB slots of one query per block
+__global__ __launch_bounds__(SCORE_THREADS) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_seg_score_screen(seg_launch L, int maxsol, const double *__restrict__ proj,
+                                                                                                              const float *__restrict__ projf,
+                                                                                                              const int *__restrict__ nsol, double eps,
+                                                                                                              int *__restrict__ counts, int spb)
+{
+    __shared__ int s_cnt[SCORE_SPB];
+    __shared__ int s_list[SCORE_SPB];
+    __shared__ int s_wave_n[SCORE_THREADS / 64];
+    const size_t base = (size_t)blockIdx.y * L.S, sbase = base * maxsol;
+    score_screen_block<false>(seg_of(L, blockIdx.y).q, L.V * maxsol, proj + sbase * 12, projf + sbase * 32, nsol + base, maxsol, eps, counts + sbase,
+                              nullptr, 0, spb, blockIdx.x, s_cnt, s_list, s_wave_n);
+}
+
+// ---- coverage-quality selection, one block per query -----------------------------------------------
+// Per-query scratch of the selection (positions in the group): state 33 words, n 2 ints,
+// list1 / area1 / bands1 for cap1 records, list2 / bands2 for cap2 candidates, merge scratch
+// for cap1 + cap2 entries.
+struct seg_cov {
+    unsigned long long *state;   // [queries of the batch][33], indexed by query (carried over rounds)
+    int *n;                      // [group][2]
+    int *list1; long long *area1; unsigned long long *bands1; int cap1;
+    int *list2; unsigned long long *bands2; int cap2;
+    int *mslot; long long *marea; unsigned char *mkeep;
+    int bands_max;
+};
+
+__global__ __launch_bounds__(COVSEL_THREADS) void k_seg_cov_records(seg_launch L, seg_cov C, const int *__restrict__ counts,
+                                                                     const int *__restrict__ nsol)
+{
+    __shared__ int s_tmp[COVSEL_THREADS / 64];
+    const int a = blockIdx.x;
+    const seg_query &sq = seg_of(L, a);
+    const size_t base = (size_t)a * L.S;
+    cov_records_block(L.V * sq.maxsol, counts + base * sq.maxsol, nsol + base, sq.maxsol, sq.box, C.state + (size_t)L.active[a] * 33,
+                      C.list1 + (size_t)a * C.cap1, C.n + 2 * a, C.cap1, s_tmp);
+}
+
+// which = 0: the records (list1), 1: the candidates (list2); blockIdx.z = position in the group.
+// Dynamic LDS: the largest band bitmap of the group.
+__global__ __launch_bounds__(256) void k_seg_coverage(seg_launch L, seg_cov C, int which, const double *__restrict__ proj, double eps)
+{
+    extern __shared__ unsigned int s_bm[];
+    __shared__ unsigned long long s_sum[256];
+    __shared__ int s_any;
+    const int a = blockIdx.z;
+    const seg_query &sq = seg_of(L, a);
+    if ((int)blockIdx.y >= sq.bands) return;
+    const int cap = which ? C.cap2 : C.cap1;
+    const int n = min(C.n[2 * a + which], cap);
+    const int *list = which ? C.list2 + (size_t)a * C.cap2 : C.list1 + (size_t)a * C.cap1;
+    unsigned long long *sums = which ? C.bands2 + (size_t)a * C.cap2 * C.bands_max : C.bands1 + (size_t)a * C.cap1 * C.bands_max;
+    const double *pq = proj + (size_t)a * L.S * sq.maxsol * 12;
+    for (int pose = blockIdx.x; pose < n; pose += gridDim.x) {
+        if (sq.separable) coverage_band(sq.q, pose, pq, list, eps, 0, sq.band_rows, sq.wpr, sums, s_bm, s_sum, s_any, blockIdx.y, sq.bands);
+        else coverage_band_direct(sq.q, pose, pq, list, eps, 0, sq.band_rows, sq.wpr, sums, s_bm, s_sum, blockIdx.y, sq.bands);
+        __syncthreads();
+    }
+}
+
+// the all-matches map of every query of the group (query_processor.cpp:154-169): sums[a][band]
+__global__ __launch_bounds__(256) void k_seg_coverage_all(seg_launch L, unsigned long long *__restrict__ sums, int bands_max)
+{
+    extern __shared__ unsigned int s_bm[];
+    __shared__ unsigned long long s_sum[256];
+    __shared__ int s_any;
+    const int a = blockIdx.z;
+    const seg_query &sq = seg_of(L, a);
+    unsigned long long *out = sums + (size_t)a * bands_max;
+    if ((int)blockIdx.y >= sq.bands) { if (threadIdx.x == 0) out[blockIdx.y] = 0ull; return; }
+    // pose 0 of a one-pose "list"; with all_matches set no projection matrix is read
+    if (sq.separable) coverage_band(sq.q, 0, nullptr, nullptr, 0.5, 1, sq.band_rows, sq.wpr, out, s_bm, s_sum, s_any, blockIdx.y, 1);
+    else coverage_band_direct(sq.q, 0, nullptr, nullptr, 0.5, 1, sq.band_rows, sq.wpr, out, s_bm, s_sum, blockIdx.y, 1);
+}
+
+__global__ __launch_bounds__(COVSEL_THREADS) void k_seg_cov_candidates(seg_launch L, seg_cov C, const int *__restrict__ counts,
+                                                                        const int *__restrict__ nsol)
+{
+    __shared__ int s_tmp[COVSEL_THREADS / 64];
+    const int a = blockIdx.x;
+    const seg_query &sq = seg_of(L, a);
+    const size_t base = (size_t)a * L.S;
+    if (C.n[2 * a] > C.cap1) {                           // truncated record list (block-uniform): k_seg_cov_final reports it
+        if (threadIdx.x == 0) C.n[2 * a + 1] = 0;
+        return;
+    }
+    cov_candidates_block(L.V * sq.maxsol, counts + base * sq.maxsol, nsol + base, sq.maxsol, sq.box, C.state + (size_t)L.active[a] * 33,
+                         C.list1 + (size_t)a * C.cap1, C.n + 2 * a, C.bands1 + (size_t)a * C.cap1 * C.bands_max, sq.bands,
+                         C.area1 + (size_t)a * 2 * C.cap1, C.list2 + (size_t)a * C.cap2, C.n + 2 * a + 1, C.cap2, s_tmp);
+}
+
+// state word 7 is set to 1 when the query had more candidates than the launch has room for: the
+// caller then runs that query through the per-query path instead.
+__global__ __launch_bounds__(COVSEL_THREADS) void k_seg_cov_final(seg_launch L, seg_cov C, int early_exit, const int *__restrict__ counts,
+                                                                   const int *__restrict__ nsol, const double *__restrict__ pose,
+                                                                   const double *__restrict__ proj)
+{
+    __shared__ cov_final_lds lds;
+    const int a = blockIdx.x;
+    const seg_query &sq = seg_of(L, a);
+    const size_t base = (size_t)a * L.S, sbase = base * sq.maxsol;
+    unsigned long long *state = C.state + (size_t)L.active[a] * 33;
+    if (C.n[2 * a] > C.cap1 || C.n[2 * a + 1] > C.cap2) {   // block-uniform
+        if (threadIdx.x == 0) state[7] = 1ull;
+        return;
+    }
+    cov_final_block(L.V * sq.maxsol, L.V, counts + sbase, nsol + base, sq.maxsol, sq.thresh, early_exit, C.list1 + (size_t)a * C.cap1,
+                    C.n + 2 * a, C.area1 + (size_t)a * 2 * C.cap1, C.list2 + (size_t)a * C.cap2, C.n + 2 * a + 1,
+                    C.bands2 + (size_t)a * C.cap2 * C.bands_max, sq.bands, C.mslot + (size_t)a * (C.cap1 + C.cap2), C.marea + (size_t)a * (C.cap1 + C.cap2),
+                    C.mkeep + (size_t)a * (C.cap1 + C.cap2), pose + sbase * 13, proj + sbase * 12, state, lds);
+}
+
+} // namespace pose_amd

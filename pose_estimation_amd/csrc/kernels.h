@@ -32,12 +32,10 @@ __device__ __forceinline__ uint32_t draw_index(draw_stream &s, uint32_t n) { ret
 // ------------------------------------------------------------------------------------------
 // query_processor_basic.cpp:136-152: m ordered picks, a pick is redrawn while its lindex
 // equals that of an earlier pick.
-__global__ void k_sample_basic(query_dev q, int m, uint64_t seed, uint32_t query_id, uint32_t hyp_begin, uint32_t hyp_count,
-                               uint32_t *__restrict__ samples)
+__device__ __forceinline__ void sample_basic_one(const query_dev &q, int m, uint64_t seed, uint32_t query_id, uint32_t hyp,
+                                                 uint32_t *__restrict__ samples, size_t i)
 {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= hyp_count) return;
-    draw_stream ds(seed, query_id, hyp_begin + i, 0);
+    draw_stream ds(seed, query_id, hyp, 0);
     uint32_t sel[4] = {NO_INDEX, NO_INDEX, NO_INDEX, NO_INDEX}, li[4] = {0, 0, 0, 0};
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
@@ -51,6 +49,14 @@ __global__ void k_sample_basic(query_dev q, int m, uint64_t seed, uint32_t query
         }
     }
     reinterpret_cast<uint4 *>(samples)[i] = make_uint4(sel[0], sel[1], sel[2], sel[3]);
+}
+
+__global__ void k_sample_basic(query_dev q, int m, uint64_t seed, uint32_t query_id, uint32_t hyp_begin, uint32_t hyp_count,
+                               uint32_t *__restrict__ samples)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= hyp_count) return;
+    sample_basic_one(q, m, seed, query_id, hyp_begin + i, samples, i);
 }
 
 // query_processor_advanced.cpp:329-440: co-occurrence prioritised accept/reject chain.
@@ -79,20 +85,14 @@ __device__ __forceinline__ uint32_t draw_at(uint64_t seed, uint32_t query_id, ui
 // bit tests instead of a merge of two sorted lists whose every step waits for the one before
 // (the slowest lane's merge sets the pace of a round), and the whole wave rebuilds the
 // intersection when a pick is accepted.  The sets are the same, so are the tuples.
+// One tuple by one wave: `hyp` is the hypothesis id, the tuple goes to samples[4 t], inter / bm are
+// the wave's LDS scratch (MAXCAM words; bm_words words when BITMAP).
 template <bool BITMAP>
-__global__ __launch_bounds__(64 * SAMPLE_ADV_WAVES) void k_sample_advanced(query_dev q, int m, uint64_t seed, uint32_t query_id,
-                                                                            uint32_t hyp_begin, uint32_t hyp_count,
-                                                                            const double *__restrict__ gain, uint32_t *__restrict__ samples,
-                                                                            int *__restrict__ status, int bm_words)
+__device__ __forceinline__ void sample_advanced_wave(const query_dev &q, int m, uint64_t seed, uint32_t query_id, uint32_t hyp, size_t t,
+                                                     const double *__restrict__ gain, uint32_t *__restrict__ samples, int *__restrict__ status,
+                                                     int bm_words, uint32_t *inter, uint32_t *bm)
 {
-    __shared__ uint32_t s_inter[SAMPLE_ADV_WAVES][MAXCAM];
-    extern __shared__ uint32_t s_cam_bits[];             // BITMAP: bm_words words per wave
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const uint32_t t = blockIdx.x * SAMPLE_ADV_WAVES + wave;
-    if (t >= hyp_count) return;                          // whole waves leave together
-    uint32_t *inter = s_inter[wave];
-    uint32_t *bm = s_cam_bits + (BITMAP ? wave * bm_words : 0);
-    const uint32_t hyp = hyp_begin + t;
+    const int lane = threadIdx.x & 63;
     const unsigned long long lt = (1ull << lane) - 1ull;  // lanes before this one
     uint32_t di = 0, dp = 0;                             // draws consumed from the index / probability streams
     uint32_t sel[4] = {NO_INDEX, NO_INDEX, NO_INDEX, NO_INDEX}, lsel[4] = {0, 0, 0, 0};
@@ -219,6 +219,21 @@ __global__ __launch_bounds__(64 * SAMPLE_ADV_WAVES) void k_sample_advanced(query
     }
 }
 
+template <bool BITMAP>
+__global__ __launch_bounds__(64 * SAMPLE_ADV_WAVES) void k_sample_advanced(query_dev q, int m, uint64_t seed, uint32_t query_id,
+                                                                            uint32_t hyp_begin, uint32_t hyp_count,
+                                                                            const double *__restrict__ gain, uint32_t *__restrict__ samples,
+                                                                            int *__restrict__ status, int bm_words)
+{
+    __shared__ uint32_t s_inter[SAMPLE_ADV_WAVES][MAXCAM];
+    extern __shared__ uint32_t s_cam_bits[];             // BITMAP: bm_words words per wave
+    const int wave = threadIdx.x >> 6;
+    const uint32_t t = blockIdx.x * SAMPLE_ADV_WAVES + wave;
+    if (t >= hyp_count) return;                          // whole waves leave together
+    sample_advanced_wave<BITMAP>(q, m, seed, query_id, hyp_begin + t, t, gain, samples, status, bm_words, s_inter[wave],
+                                 s_cam_bits + (BITMAP ? wave * bm_words : 0));
+}
+
 // Float32 copy of a projection matrix for the scoring screen: 32 floats, every entry twice
 // (operand pairs of the packed instructions), then the additive constant B of the screen's
 // error bound twice (derivation at k_score_screen).
@@ -273,11 +288,10 @@ __device__ __forceinline__ void load_obs(const query_dev &q, uint32_t idx, doubl
 }
 
 // P3P branch of the RANSAC step (query_processor_basic.cpp:228-291): one hypothesis per lane.
-__global__ __launch_bounds__(64) void k_solve_p3p(query_dev q, uint32_t hyp_count, const uint32_t *__restrict__ samples, double *__restrict__ proj,
-                            double *__restrict__ pose, int *__restrict__ nsol, float *__restrict__ projf, double eps)
+// h indexes samples / nsol and (times 4) the pose slots of the arrays passed in.
+__device__ __forceinline__ void solve_p3p_one(const query_dev &q, size_t h, const uint32_t *__restrict__ samples, double *__restrict__ proj,
+                                              double *__restrict__ pose, int *__restrict__ nsol, float *__restrict__ projf, double eps)
 {
-    const uint32_t h = blockIdx.x * blockDim.x + threadIdx.x;
-    if (h >= hyp_count) return;
     const uint4 s = reinterpret_cast<const uint4 *>(samples)[h];
     const uint32_t id[3] = {s.x, s.y, s.z};
     double f[3][3], W[3][3];
@@ -298,6 +312,14 @@ __global__ __launch_bounds__(64) void k_solve_p3p(query_dev q, uint32_t hyp_coun
 #pragma unroll
         for (int k = 0; k < 4; ++k) store_pose(proj, pose, (size_t)h * P3P_MAXSOL + k, q.focal, C[k], R[k], projf, q, eps);
     }
+}
+
+__global__ __launch_bounds__(64) void k_solve_p3p(query_dev q, uint32_t hyp_count, const uint32_t *__restrict__ samples, double *__restrict__ proj,
+                            double *__restrict__ pose, int *__restrict__ nsol, float *__restrict__ projf, double eps)
+{
+    const uint32_t h = blockIdx.x * blockDim.x + threadIdx.x;
+    if (h >= hyp_count) return;
+    solve_p3p_one(q, h, samples, proj, pose, nsol, projf, eps);
 }
 
 // Converts a P4Pf solution (f, R, t) into the stored pose (basic.cpp:195-198): C = -R^T t, Rc = R^T.
@@ -355,9 +377,12 @@ __device__ __forceinline__ void p4pf_fetch(const query_dev &q, const uint32_t *_
     }
 }
 
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_p4pf_elim(query_dev q, uint32_t hyp_count, const uint32_t *__restrict__ samples,
-                                                  const double *__restrict__ m2d_in, const double *__restrict__ M3D_in,
-                                                  double *__restrict__ Arows, int *__restrict__ status, int batch)
+// The block's share of `hyp_count` systems: batches bx, bx + gx, ...  Arows points at the first
+// system's tail column; consecutive tail entries of one system lie `tail_stride` doubles apart.
+__device__ __forceinline__ void p4pf_elim_block(const query_dev &q, uint32_t hyp_count, const uint32_t *__restrict__ samples,
+                                                const double *__restrict__ m2d_in, const double *__restrict__ M3D_in,
+                                                double *__restrict__ Arows, size_t tail_stride, int *__restrict__ status, int batch,
+                                                uint32_t bx, uint32_t gx)
 {
     __shared__ double cf[ELIM_BATCH][43];
     __shared__ int st_s[ELIM_BATCH];
@@ -366,7 +391,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     const int lane = threadIdx.x;
     for (int i = lane; i < 32 * ELIM_TAB_VEC; i += 64) tab[i] = reinterpret_cast<const uint4 *>(c_elim_tab)[i];
     const uint32_t nbatch = (hyp_count + batch - 1) / batch;
-    for (uint32_t b = blockIdx.x; b < nbatch; b += gridDim.x) {
+    for (uint32_t b = bx; b < nbatch; b += gx) {
         if (lane < batch) {
             const size_t h = (size_t)b * batch + lane;
             int st = -1;
@@ -395,20 +420,27 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             if ((size_t)b * batch + 4 * i >= hyp_count) break;
             const int st = st_s[sys];
             const bool live = h < hyp_count;
-            const int rc = p4pf_elim_wave(&cf[sys][0], tab, pbuf[lane >> 4], Arows + (live ? h : 0), (size_t)hyp_count, live && st == 0);
+            const int rc = p4pf_elim_wave(&cf[sys][0], tab, pbuf[lane >> 4], Arows + (live ? h : 0), tail_stride, live && st == 0);
             if ((lane & 15) == 0 && live) status[h] = st != 0 ? -1 : rc;
         }
         __syncthreads();
     }
 }
 
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_p4pf_elim(query_dev q, uint32_t hyp_count, const uint32_t *__restrict__ samples,
+                                                  const double *__restrict__ m2d_in, const double *__restrict__ M3D_in,
+                                                  double *__restrict__ Arows, int *__restrict__ status, int batch)
+{
+    p4pf_elim_block(q, hyp_count, samples, m2d_in, M3D_in, Arows, (size_t)hyp_count, status, batch, blockIdx.x, gridDim.x);
+}
+
 // P4Pf, stage C: one hypothesis per lane.  Action matrix -> accepted roots -> (f, R, t).
 // With proj != null the solutions go to the pose slots of the RANSAC pipeline, otherwise to
 // the flat arrays of the batch entry point.
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_p4pf_finish(query_dev q, uint32_t hyp_count, const uint32_t *__restrict__ samples, const double *__restrict__ m2d_in,
-                              const double *__restrict__ M3D_in, const double *__restrict__ Arows, const int *__restrict__ status,
+__device__ __forceinline__ void p4pf_finish_block(const query_dev &q, uint32_t hyp_count, const uint32_t *__restrict__ samples, const double *__restrict__ m2d_in,
+                              const double *__restrict__ M3D_in, const double *__restrict__ Arows, size_t tail_stride, const int *__restrict__ status,
                               double *__restrict__ proj, double *__restrict__ pose, int *__restrict__ nsol, double *__restrict__ fo,
-                              double *__restrict__ Ro, double *__restrict__ to, float *__restrict__ projf, double eps)
+                              double *__restrict__ Ro, double *__restrict__ to, float *__restrict__ projf, double eps, uint32_t bx)
 {
     // Accepted roots wait here for the pose recovery: hypotheses have 0..10 of them (1.6 on
     // average), so recovering "root s of my hypothesis" in lock step would keep a third of the
@@ -418,7 +450,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     __shared__ p4pf_root s_root[128];
     __shared__ unsigned short s_meta[128];               // source lane | root index << 8
     const int lane = threadIdx.x;
-    const size_t h0 = (size_t)blockIdx.x * blockDim.x, h = h0 + lane;
+    const size_t h0 = (size_t)bx * blockDim.x, h = h0 + lane;
     const bool live = h < hyp_count;
     int n = live ? status[h] : -1;
     p4pf_root roots[10];
@@ -429,7 +461,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         p4pf_normalise(m2d, M3D, pb);
         double tl[5][15], a[50];
 #pragma unroll
-        for (int i = 0; i < P4PF_TAIL; ++i) tl[i / 15][i % 15] = Arows[(size_t)i * hyp_count + h];
+        for (int i = 0; i < P4PF_TAIL; ++i) tl[i / 15][i % 15] = Arows[(size_t)i * tail_stride + h];
         n = p4pf_reduce_tail(tl, a);
         if (n == 0) n = p4pf_roots_sextic(a, pb, roots);
     }
@@ -482,6 +514,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         }
     }
     recover(qn);
+}
+
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_p4pf_finish(query_dev q, uint32_t hyp_count, const uint32_t *__restrict__ samples, const double *__restrict__ m2d_in,
+                              const double *__restrict__ M3D_in, const double *__restrict__ Arows, const int *__restrict__ status,
+                              double *__restrict__ proj, double *__restrict__ pose, int *__restrict__ nsol, double *__restrict__ fo,
+                              double *__restrict__ Ro, double *__restrict__ to, float *__restrict__ projf, double eps)
+{
+    p4pf_finish_block(q, hyp_count, samples, m2d_in, M3D_in, Arows, (size_t)hyp_count, status, proj, pose, nsol, fo, Ro, to, projf, eps, blockIdx.x);
 }
 
 // Raw batched solver kernels for the parity entry points (inputs straight from the caller).
@@ -703,17 +743,15 @@ __device__ __forceinline__ void load_posef_uniform(const float *__restrict__ pro
 }
 
 template <bool MASK>
-__global__ __launch_bounds__(SCORE_THREADS) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_score_screen(query_dev q, int nslots, const double *__restrict__ proj,
-                                                                const float *__restrict__ projf, const int *__restrict__ nsol,
-                                                                int maxsol, double eps, int *__restrict__ counts,
-                                                                unsigned long long *__restrict__ mask, int words_per_pose, int spb)
+__device__ __forceinline__ void score_screen_block(const query_dev &q, int nslots, const double *__restrict__ proj,
+                                                   const float *__restrict__ projf, const int *__restrict__ nsol,
+                                                   int maxsol, double eps, int *__restrict__ counts,
+                                                   unsigned long long *__restrict__ mask, int words_per_pose, int spb, int bx,
+                                                   int *s_cnt, int *s_list, int *s_wave_n)
 {
     constexpr int KC = SCREEN_KC;
-    __shared__ int s_cnt[SCORE_SPB];
-    __shared__ int s_list[SCORE_SPB];
-    __shared__ int s_wave_n[SCORE_THREADS / 64];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int slot0 = blockIdx.x * spb;
+    const int slot0 = bx * spb;
     {
         const int slot = slot0 + tid;
         bool valid = tid < spb && slot < nslots;
@@ -831,6 +869,18 @@ __global__ __launch_bounds__(SCORE_THREADS) __attribute__((amdgpu_waves_per_eu(6
     if (tid < spb && slot0 + tid < nslots) counts[slot0 + tid] = s_cnt[tid];
 }
 
+template <bool MASK>
+__global__ __launch_bounds__(SCORE_THREADS) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_score_screen(query_dev q, int nslots, const double *__restrict__ proj,
+                                                                const float *__restrict__ projf, const int *__restrict__ nsol,
+                                                                int maxsol, double eps, int *__restrict__ counts,
+                                                                unsigned long long *__restrict__ mask, int words_per_pose, int spb)
+{
+    __shared__ int s_cnt[SCORE_SPB];
+    __shared__ int s_list[SCORE_SPB];
+    __shared__ int s_wave_n[SCORE_THREADS / 64];
+    score_screen_block<MASK>(q, nslots, proj, projf, nsol, maxsol, eps, counts, mask, words_per_pose, spb, blockIdx.x, s_cnt, s_list, s_wave_n);
+}
+
 // ------------------------------------------------------------------------------------------
 // Coverage area (query_processor.cpp:126-169): the number of pixels covered by the clamped
 // coverage boxes of a pose's inliers.  all_matches != 0 takes every correspondence (the
@@ -856,11 +906,12 @@ constexpr int COV_UNROLL = 8;
 // One (pose, band) of k_coverage by the whole block; every early return is taken by all threads.
 __device__ __forceinline__ void coverage_band(const query_dev &q, int pose, const double *__restrict__ proj, const int *__restrict__ slots,
                                               double eps, int all_matches, int band_rows, int words_per_row,
-                                              unsigned long long *__restrict__ band_sums, unsigned int *s_bm, unsigned long long *s_sum, int &s_any)
+                                              unsigned long long *__restrict__ band_sums, unsigned int *s_bm, unsigned long long *s_sum, int &s_any,
+                                              int band, int nbands)
 {
     const int tid = threadIdx.x;
-    unsigned long long *out = band_sums + (size_t)pose * gridDim.y + blockIdx.y;
-    const int row0 = blockIdx.y * band_rows, row1 = min(q.height, row0 + band_rows);
+    unsigned long long *out = band_sums + (size_t)pose * nbands + band;
+    const int row0 = band * band_rows, row1 = min(q.height, row0 + band_rows);
     const int cover = (int)ceilf((float)q.width / 20.0f), h = cover / 2;
     if (h == 0) { if (tid == 0) *out = 0ull; return; }       // every box is empty
     const int nh = (row1 - row0) + 2 * h - 1;                // keypoint rows y_base .. y_base + nh - 1 reach into the band
@@ -974,17 +1025,18 @@ __global__ __launch_bounds__(256) void k_coverage(query_dev q, int nposes, const
     __shared__ int s_any;
     const int n = nposes_dev ? *nposes_dev : nposes;
     for (int pose = blockIdx.x; pose < n; pose += gridDim.x) {
-        coverage_band(q, pose, proj, slots, eps, all_matches, band_rows, words_per_row, band_sums, s_bm, s_sum, s_any);
+        coverage_band(q, pose, proj, slots, eps, all_matches, band_rows, words_per_row, band_sums, s_bm, s_sum, s_any, blockIdx.y, gridDim.y);
         __syncthreads();
     }
 }
 
 __device__ __forceinline__ void coverage_band_direct(const query_dev &q, int pose, const double *__restrict__ proj, const int *__restrict__ slots,
                                                      double eps, int all_matches, int band_rows, int words_per_row,
-                                                     unsigned long long *__restrict__ band_sums, unsigned int *s_bm, unsigned long long *s_sum)
+                                                     unsigned long long *__restrict__ band_sums, unsigned int *s_bm, unsigned long long *s_sum,
+                                                     int band, int nbands)
 {
     const int tid = threadIdx.x;
-    const int row0 = blockIdx.y * band_rows, row1 = min(q.height, row0 + band_rows);
+    const int row0 = band * band_rows, row1 = min(q.height, row0 + band_rows);
     const int nwords = (row1 - row0) * words_per_row;
     for (int i = tid; i < nwords; i += blockDim.x) s_bm[i] = 0u;
     __syncthreads();
@@ -1037,7 +1089,7 @@ __device__ __forceinline__ void coverage_band_direct(const query_dev &q, int pos
     s_sum[tid] = a;
     __syncthreads();
     for (int o = 128; o > 0; o >>= 1) { if (tid < o) s_sum[tid] += s_sum[tid + o]; __syncthreads(); }
-    if (tid == 0) band_sums[(size_t)pose * gridDim.y + blockIdx.y] = s_sum[0];
+    if (tid == 0) band_sums[(size_t)pose * nbands + band] = s_sum[0];
 }
 
 __global__ __launch_bounds__(256) void k_coverage_direct(query_dev q, int nposes, const int *__restrict__ nposes_dev, const double *__restrict__ proj,
@@ -1048,7 +1100,7 @@ __global__ __launch_bounds__(256) void k_coverage_direct(query_dev q, int nposes
     __shared__ unsigned long long s_sum[256];
     const int n = nposes_dev ? *nposes_dev : nposes;
     for (int pose = blockIdx.x; pose < n; pose += gridDim.x) {
-        coverage_band_direct(q, pose, proj, slots, eps, all_matches, band_rows, words_per_row, band_sums, s_bm, s_sum);
+        coverage_band_direct(q, pose, proj, slots, eps, all_matches, band_rows, words_per_row, band_sums, s_bm, s_sum, blockIdx.y, gridDim.y);
         __syncthreads();
     }
 }
@@ -1099,11 +1151,11 @@ __device__ __forceinline__ T covsel_block_scan(T v, T identity, OP op, T *s_tmp,
 struct covsel_max { template <typename T> __device__ T operator()(T a, T b) const { return a > b ? a : b; } };
 struct covsel_add { template <typename T> __device__ T operator()(T a, T b) const { return a + b; } };
 
-__global__ __launch_bounds__(COVSEL_THREADS) void k_cov_records(int nslots, const int *__restrict__ counts, const int *__restrict__ nsol, int maxsol,
-                                                                 long long box, const unsigned long long *__restrict__ state,
-                                                                 int *__restrict__ list1, int *__restrict__ n1)
+// list1 holds at most cap1 entries; *n1 gets the number found (beyond cap1 the list is truncated).
+__device__ __forceinline__ void cov_records_block(int nslots, const int *__restrict__ counts, const int *__restrict__ nsol, int maxsol,
+                                                  long long box, const unsigned long long *__restrict__ state,
+                                                  int *__restrict__ list1, int *__restrict__ n1, int cap1, int *s_tmp)
 {
-    __shared__ int s_tmp[COVSEL_THREADS / 64];
     const int tid = threadIdx.x;
     const long long carried = (long long)state[0];
     int run = 0;                                         // largest count of all earlier valid slots
@@ -1131,11 +1183,19 @@ __global__ __launch_bounds__(COVSEL_THREADS) void k_cov_records(int nslots, cons
         int total;
         int off = n + covsel_block_scan(mine, 0, covsel_add(), s_tmp, total);
 #pragma unroll
-        for (int k = 0; k < COVSEL_K; ++k) if (flags & (1u << k)) list1[off++] = base + tid * COVSEL_K + k;
+        for (int k = 0; k < COVSEL_K; ++k) if (flags & (1u << k)) { if (off < cap1) list1[off] = base + tid * COVSEL_K + k; ++off; }
         n += total;
         run = max(run, tilemax);
     }
     if (tid == 0) *n1 = n;
+}
+
+__global__ __launch_bounds__(COVSEL_THREADS) void k_cov_records(int nslots, const int *__restrict__ counts, const int *__restrict__ nsol, int maxsol,
+                                                                 long long box, const unsigned long long *__restrict__ state,
+                                                                 int *__restrict__ list1, int *__restrict__ n1)
+{
+    __shared__ int s_tmp[COVSEL_THREADS / 64];
+    cov_records_block(nslots, counts, nsol, maxsol, box, state, list1, n1, nslots, s_tmp);
 }
 
 // areas of a list entry = sum of its band sums
@@ -1153,13 +1213,14 @@ __device__ __forceinline__ int covsel_lower_bound(const int *__restrict__ a, int
     return lo;
 }
 
-__global__ __launch_bounds__(COVSEL_THREADS) void k_cov_candidates(int nslots, const int *__restrict__ counts, const int *__restrict__ nsol, int maxsol,
-                                                                    long long box, const unsigned long long *__restrict__ state,
-                                                                    const int *__restrict__ list1, const int *__restrict__ n1p,
-                                                                    const unsigned long long *__restrict__ bands1, int nbands,
-                                                                    long long *__restrict__ area1, int *__restrict__ list2, int *__restrict__ n2)
+// list2 holds at most cap2 entries; *n2 gets the number found (beyond cap2: the list is truncated
+// and the caller must not use it).
+__device__ __forceinline__ void cov_candidates_block(int nslots, const int *__restrict__ counts, const int *__restrict__ nsol, int maxsol,
+                                                     long long box, const unsigned long long *__restrict__ state,
+                                                     const int *__restrict__ list1, const int *__restrict__ n1p,
+                                                     const unsigned long long *__restrict__ bands1, int nbands,
+                                                     long long *__restrict__ area1, int *__restrict__ list2, int *__restrict__ n2, int cap2, int *s_tmp)
 {
-    __shared__ int s_tmp[COVSEL_THREADS / 64];
     const int tid = threadIdx.x;
     const int n1 = *n1p;
     const long long carried = (long long)state[0];
@@ -1194,10 +1255,20 @@ __global__ __launch_bounds__(COVSEL_THREADS) void k_cov_candidates(int nslots, c
         int total;
         int off = n + covsel_block_scan(mine, 0, covsel_add(), s_tmp, total);
 #pragma unroll
-        for (int k = 0; k < COVSEL_K; ++k) if (flags & (1u << k)) list2[off++] = s0 + k;
+        for (int k = 0; k < COVSEL_K; ++k) if (flags & (1u << k)) { if (off < cap2) list2[off] = s0 + k; ++off; }
         n += total;
     }
     if (tid == 0) *n2 = n;
+}
+
+__global__ __launch_bounds__(COVSEL_THREADS) void k_cov_candidates(int nslots, const int *__restrict__ counts, const int *__restrict__ nsol, int maxsol,
+                                                                    long long box, const unsigned long long *__restrict__ state,
+                                                                    const int *__restrict__ list1, const int *__restrict__ n1p,
+                                                                    const unsigned long long *__restrict__ bands1, int nbands,
+                                                                    long long *__restrict__ area1, int *__restrict__ list2, int *__restrict__ n2)
+{
+    __shared__ int s_tmp[COVSEL_THREADS / 64];
+    cov_candidates_block(nslots, counts, nsol, maxsol, box, state, list1, n1p, bands1, nbands, area1, list2, n2, nslots, s_tmp);
 }
 
 // Replay in slot order over records + candidates, in parallel: (1) the two lists are merged by
@@ -1206,19 +1277,26 @@ __global__ __launch_bounds__(COVSEL_THREADS) void k_cov_candidates(int nslots, c
 // after the first step at whose end the kept pose -- the last keeper of that step -- has >= thresh
 // inliers; without such a step the last keeper of the chunk stays.
 // mslot / marea / mkeep: scratch for n1 + n2 entries.
-__global__ __launch_bounds__(COVSEL_THREADS) void k_cov_final(int nslots, int steps_in_chunk, const int *__restrict__ counts, const int *__restrict__ nsol,
-                                                               int maxsol, unsigned int thresh, int early_exit, const int *__restrict__ list1,
-                                                               const int *__restrict__ n1p, const long long *__restrict__ area1,
-                                                               const int *__restrict__ list2, const int *__restrict__ n2p,
-                                                               const unsigned long long *__restrict__ bands2, int nbands,
-                                                               int *__restrict__ mslot, long long *__restrict__ marea, unsigned char *__restrict__ mkeep,
-                                                               const double *__restrict__ pose, const double *__restrict__ proj,
-                                                               unsigned long long *__restrict__ state)
+struct cov_final_lds {
+    long long tilemax[COVSEL_THREADS / 64];
+    int exit_i[COVSEL_THREADS / 64], last_i[COVSEL_THREADS / 64];
+    unsigned long long cnt[COVSEL_THREADS / 64];
+    int steps, kept;
+};
+
+__device__ __forceinline__ void cov_final_block(int nslots, int steps_in_chunk, const int *__restrict__ counts, const int *__restrict__ nsol,
+                                                int maxsol, unsigned int thresh, int early_exit, const int *__restrict__ list1,
+                                                const int *__restrict__ n1p, const long long *__restrict__ area1,
+                                                const int *__restrict__ list2, const int *__restrict__ n2p,
+                                                const unsigned long long *__restrict__ bands2, int nbands,
+                                                int *__restrict__ mslot, long long *__restrict__ marea, unsigned char *__restrict__ mkeep,
+                                                const double *__restrict__ pose, const double *__restrict__ proj,
+                                                unsigned long long *__restrict__ state, cov_final_lds &L)
 {
-    __shared__ long long s_tilemax[COVSEL_THREADS / 64];
-    __shared__ int s_exit[COVSEL_THREADS / 64], s_last[COVSEL_THREADS / 64];
-    __shared__ unsigned long long s_cnt[COVSEL_THREADS / 64];
-    __shared__ int s_steps, s_kept;
+    long long *s_tilemax = L.tilemax;
+    int *s_exit = L.exit_i, *s_last = L.last_i;
+    unsigned long long *s_cnt = L.cnt;
+    int &s_steps = L.steps, &s_kept = L.kept;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n1 = *n1p, n2 = *n2p, N = n1 + n2;
     const long long carried = (long long)state[0];
@@ -1295,6 +1373,20 @@ __global__ __launch_bounds__(COVSEL_THREADS) void k_cov_final(int nslots, int st
         if (tid < 13) out[8 + tid] = pose[(size_t)bs * 13 + tid];
         if (tid < 12) out[21 + tid] = proj[(size_t)bs * 12 + tid];
     }
+}
+
+__global__ __launch_bounds__(COVSEL_THREADS) void k_cov_final(int nslots, int steps_in_chunk, const int *__restrict__ counts, const int *__restrict__ nsol,
+                                                               int maxsol, unsigned int thresh, int early_exit, const int *__restrict__ list1,
+                                                               const int *__restrict__ n1p, const long long *__restrict__ area1,
+                                                               const int *__restrict__ list2, const int *__restrict__ n2p,
+                                                               const unsigned long long *__restrict__ bands2, int nbands,
+                                                               int *__restrict__ mslot, long long *__restrict__ marea, unsigned char *__restrict__ mkeep,
+                                                               const double *__restrict__ pose, const double *__restrict__ proj,
+                                                               unsigned long long *__restrict__ state)
+{
+    __shared__ cov_final_lds L;
+    cov_final_block(nslots, steps_in_chunk, counts, nsol, maxsol, thresh, early_exit, list1, n1p, area1, list2, n2p, bands2, nbands, mslot, marea, mkeep,
+                    pose, proj, state, L);
 }
 
 // ------------------------------------------------------------------------------------------

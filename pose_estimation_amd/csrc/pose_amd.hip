@@ -3,6 +3,7 @@
 // numeric result comes from the HIP kernels in kernels.h.
 #include "../../include/pose_amd.h"
 #include "kernels.h"
+#include "batch_seg.h"
 #include <algorithm>
 #include <atomic>
 #include <mutex>
@@ -87,6 +88,10 @@ struct pose_amd_ctx {
                                    // every event is one more command for the GPU's command processor)
     // batch entry point: child contexts (one stream each)
     std::vector<pose_amd_ctx *> lanes;
+    // segmented batch (many queries per launch): packed queries, descriptor table, per-hypothesis arrays, selection scratch
+    dev_buf sg_qpack, sg_qtab, sg_active, sg_samples, sg_sstatus, sg_arows, sg_pstatus, sg_proj, sg_pose, sg_projf, sg_nsol, sg_counts, sg_state, sg_n,
+        sg_list1, sg_area1, sg_bands1, sg_list2, sg_bands2, sg_mslot, sg_marea, sg_mkeep, sg_allsums;
+    pin_buf sgh_qpack, sgh_qtab, sgh_active, sgh_state, sgh_allsums;
     // hypotheses
     uint32_t hyp_count = 0;
     int solver = POSE_AMD_SOLVER_P4PF;
@@ -268,10 +273,12 @@ void pose_amd_destroy(pose_amd_ctx *c)
                        &c->sample_status, &c->proj, &c->pose, &c->nsol, &c->counts, &c->sel, &c->bitmaps, &c->areas,
                        &c->maskw, &c->arows, &c->pstatus, &c->projf, &c->feat, &c->vlist, &c->vcount, &c->arows2, &c->pstatus2, &c->vlist2, &c->vcount2, &c->in0, &c->in1, &c->in2, &c->out0, &c->out1, &c->out2, &c->out3,
                        &c->cov_state, &c->cov_n, &c->cov_list1, &c->cov_bands1, &c->cov_area1, &c->cov_list2, &c->cov_bands2, &c->cov_mslot, &c->cov_marea,
-                       &c->cov_mkeep};
+                       &c->cov_mkeep, &c->sg_qpack, &c->sg_qtab, &c->sg_active, &c->sg_samples, &c->sg_sstatus, &c->sg_arows, &c->sg_pstatus, &c->sg_proj,
+                       &c->sg_pose, &c->sg_projf, &c->sg_nsol, &c->sg_counts, &c->sg_state, &c->sg_n, &c->sg_list1, &c->sg_area1, &c->sg_bands1, &c->sg_list2,
+                       &c->sg_bands2, &c->sg_mslot, &c->sg_marea, &c->sg_mkeep, &c->sg_allsums};
     for (dev_buf *b : bufs) if (b->p) (void)hipFree(b->p);
     if (c->qstage) (void)hipHostFree(c->qstage);
-    pin_buf *pins[] = {&c->band_host, &c->h_words};
+    pin_buf *pins[] = {&c->band_host, &c->h_words, &c->sgh_qpack, &c->sgh_qtab, &c->sgh_active, &c->sgh_state, &c->sgh_allsums};
     for (pin_buf *b : pins) if (b->p) (void)hipHostFree(b->p);
     for (int i = 0; i < 6; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
     for (int i = 0; i < 6; ++i) if (c->ev2[i]) (void)hipEventDestroy(c->ev2[i]);
@@ -1092,6 +1099,311 @@ int pose_amd_ransac_run(pose_amd_ctx *ctx, const pose_amd_params *prm, pose_amd_
 }
 
 
+// ---- many queries, segmented launches ------------------------------------------------------------
+// Coverage geometry of an image (the choices of coverage_dev for short lists of poses).
+static bool coverage_geometry(int width, int height, int &band_rows, int &bands, int &wpr, int &separable, size_t &lds)
+{
+    wpr = (width + 31) / 32;
+    if ((size_t)wpr * 4 > 48 * 1024) return false;
+    const int half = (int)std::ceil((float)width / 20.0f) / 2;
+    const int lds_rows = (64 * 1024) / (wpr * 4);
+    const int sep_rows = (lds_rows * 8) / 9 - 2 * half - 1;
+    separable = sep_rows >= 8;
+    const int max_rows = separable ? std::min(height, sep_rows) : std::max(1, std::min(height, (48 * 1024) / (wpr * 4)));
+    band_rows = std::max(1, std::min(max_rows, cdiv(height, 16)));
+    bands = cdiv(height, band_rows);
+    if (separable) {
+        const int nh = band_rows + 2 * half - 1;
+        lds = (size_t)(nh + (nh + 7) / 8) * wpr * 4;
+    } else {
+        lds = (size_t)band_rows * wpr * 4;
+    }
+    return true;
+}
+
+// QueryProcessorBasic/Advanced::Process for many queries with the reference's selection (coverage
+// quality), many queries per launch: all queries are packed and uploaded once; rounds of
+// 1 024, 4 096, ... steps run over the queries that have not finished (all of them in one launch
+// sequence per solver), one download of the per-query selection state ends a round.  Results equal
+// the per-query sequence set_query + sample + ransac_run.  fallback[i] is set for queries that must
+// take the per-query path instead (more candidates than a launch has room for).
+static int ransac_batch_segmented(pose_amd_ctx *ctx, int nq, const pose_amd_query *queries, int sample_mode, uint64_t seed, uint32_t budget,
+                                  const pose_amd_params *prm, pose_amd_result *results, std::vector<char> &fallback)
+{
+    const bool advanced = sample_mode == POSE_AMD_SAMPLE_ADVANCED;
+    const bool early = prm->early_exit != 0;
+    fallback.assign((size_t)nq, 0);
+    int rc;
+    // ---- layout of the packed correspondence arrays and validation ------------------------------
+    struct qinfo { size_t off; size_t b; size_t cam_off_at, cam_ids_at; bool live; int maxsol; };
+    std::vector<qinfo> qi((size_t)nq);
+    size_t total = 0;
+    for (int i = 0; i < nq; ++i) {
+        const pose_amd_query &q = queries[i];
+        memset(&results[i], 0, sizeof results[i]);
+        if (q.n < 0 || q.width <= 0 || q.height <= 0 || (q.n && (!q.kx || !q.ky || !q.X || !q.Y || !q.Z)) || !(q.focal >= 0.0))
+            return fail(ctx, POSE_AMD_EINVAL, ("ransac_batch: query " + std::to_string(i) + ": set_query: bad argument").c_str());
+        const int m = q.focal == 0.0 ? 4 : 3;
+        int distinct = std::min(q.n, 4);
+        if (q.lindex) {
+            uint32_t seen[4];
+            distinct = 0;
+            for (int k = 0; k < q.n && distinct < 4; ++k) {
+                bool dup = false;
+                for (int j = 0; j < distinct; ++j) dup = dup || seen[j] == q.lindex[k];
+                if (!dup) seen[distinct++] = q.lindex[k];
+            }
+        }
+        if (q.n <= 0) return fail(ctx, POSE_AMD_ESTATE, ("ransac_batch: query " + std::to_string(i) + ": sample: no query set").c_str());
+        if (q.n < m || distinct < m)
+            return fail(ctx, POSE_AMD_EINVAL, ("ransac_batch: query " + std::to_string(i) + ": sample: fewer correspondences (distinct keypoints) than the minimal sample size").c_str());
+        qinfo &e = qi[(size_t)i];
+        e.b = (((size_t)q.n * 4) + 255) / 256 * 256;
+        e.off = total;
+        e.maxsol = q.focal == 0.0 ? P4PF_MAXSOL : P3P_MAXSOL;
+        total += e.b * (q.lindex ? 6 : 5);
+        e.cam_off_at = e.cam_ids_at = 0;
+        if (advanced) {
+            if (!q.cam_off || !q.cam_ids || q.cam_off[0] != 0)
+                return fail(ctx, POSE_AMD_EINVAL, ("ransac_batch: query " + std::to_string(i) + ": set_camsets: no query or bad argument").c_str());
+            bool any5 = false;
+            for (int k = 0; k < q.n; ++k) {
+                if (q.cam_off[k + 1] < q.cam_off[k]) return fail(ctx, POSE_AMD_EINVAL, "ransac_batch: set_camsets: offsets must be non-decreasing");
+                const uint32_t sz = q.cam_off[k + 1] - q.cam_off[k];
+                if (sz > (uint32_t)MAXCAM) return fail(ctx, POSE_AMD_EINVAL, "ransac_batch: set_camsets: a camera set exceeds 128 entries");
+                any5 |= sz >= 5;
+                for (uint32_t c = q.cam_off[k] + 1; c < q.cam_off[k + 1]; ++c)
+                    if (q.cam_ids[c] <= q.cam_ids[c - 1]) return fail(ctx, POSE_AMD_EINVAL, "ransac_batch: set_camsets: ids must be strictly increasing per set");
+            }
+            if (!any5) return fail(ctx, POSE_AMD_EINVAL, ("ransac_batch: query " + std::to_string(i) + ": set_camsets: no correspondence has >= 5 cameras").c_str());
+            e.cam_off_at = total;
+            total += (((size_t)q.n + 1) * 4 + 255) / 256 * 256;
+            e.cam_ids_at = total;
+            total += ((size_t)std::max<uint32_t>(q.cam_off[q.n], 1u) * 4 + 255) / 256 * 256;
+        }
+        const unsigned thresh = std::min((unsigned)q.n / prm->inlier_divisor, (unsigned)prm->inlier_absolute);
+        e.live = budget > 0 && !(early && thresh == 0);             // otherwise the reference's loop body never runs
+    }
+    if ((rc = ensure(ctx, ctx->sg_qpack, total)) || (rc = ensure_pinned(ctx, ctx->sgh_qpack, total)) ||
+        (rc = ensure(ctx, ctx->sg_qtab, (size_t)nq * sizeof(seg_query))) || (rc = ensure_pinned(ctx, ctx->sgh_qtab, (size_t)nq * sizeof(seg_query))) ||
+        (rc = ensure(ctx, ctx->sg_state, (size_t)nq * 33 * 8)) || (rc = ensure_pinned(ctx, ctx->sgh_state, (size_t)nq * 33 * 8)))
+        return rc;
+    // ---- pack (a few host threads: the copies and the scans for the screens' bounds) -------------
+    seg_query *qt = (seg_query *)ctx->sgh_qtab.p;
+    char *hp = (char *)ctx->sgh_qpack.p, *dp = (char *)ctx->sg_qpack.p;
+    size_t lds_cov = 0;
+    int bands_max = 1, bm_max = 0;
+    std::atomic<int> bad_geometry(0);
+    {
+        std::atomic<int> next(0);
+        auto pack = [&]() {
+            for (;;) {
+                const int i = next.fetch_add(1);
+                if (i >= nq) return;
+                const pose_amd_query &q = queries[i];
+                const qinfo &e = qi[(size_t)i];
+                const void *src[6] = {q.kx, q.ky, q.X, q.Y, q.Z, q.lindex};
+                for (int a = 0; a < (q.lindex ? 6 : 5); ++a) memcpy(hp + e.off + e.b * a, src[a], (size_t)q.n * 4);
+                seg_query &sq = qt[i];
+                memset(&sq, 0, sizeof sq);
+                sq.q.n = q.n; sq.q.width = q.width; sq.q.height = q.height; sq.q.focal = q.focal;
+                sq.q.kx = (const float *)(dp + e.off); sq.q.ky = (const float *)(dp + e.off + e.b); sq.q.X = (const float *)(dp + e.off + 2 * e.b);
+                sq.q.Y = (const float *)(dp + e.off + 3 * e.b); sq.q.Z = (const float *)(dp + e.off + 4 * e.b);
+                sq.q.lindex = q.lindex ? (const uint32_t *)(dp + e.off + 5 * e.b) : nullptr;
+                float xm = 0.f, um = 0.f;
+                bool finite = true;
+                for (int k = 0; k < q.n; ++k) {
+                    const float a = std::fmax(std::fabs(q.X[k]), std::fmax(std::fabs(q.Y[k]), std::fabs(q.Z[k])));
+                    const float u = (float)std::fmax(std::fabs((double)q.kx[k] - q.width / 2.0), std::fabs((double)q.ky[k] - q.height / 2.0));
+                    finite = finite && a == a && u == u;
+                    xm = std::fmax(xm, a); um = std::fmax(um, u);
+                }
+                sq.q.xmax = finite ? xm : NAN; sq.q.umax = finite ? um * 1.000001f : NAN;
+                sq.query_id = q.query_id;
+                sq.maxsol = e.maxsol;
+                sq.thresh = std::min((unsigned)q.n / prm->inlier_divisor, (unsigned)prm->inlier_absolute);
+                const long long cover = (long long)std::ceil((float)q.width / 20.0f);
+                sq.box = (long long)(2 * (cover / 2)) * (2 * (cover / 2));
+                size_t lds = 0;
+                if (!coverage_geometry(q.width, q.height, sq.band_rows, sq.bands, sq.wpr, sq.separable, lds)) { bad_geometry = 1; continue; }
+                if (advanced) {
+                    memcpy(hp + e.cam_off_at, q.cam_off, ((size_t)q.n + 1) * 4);
+                    memcpy(hp + e.cam_ids_at, q.cam_ids, (size_t)q.cam_off[q.n] * 4);
+                    sq.q.cam_off = (const uint32_t *)(dp + e.cam_off_at); sq.q.cam_ids = (const uint32_t *)(dp + e.cam_ids_at);
+                    uint32_t cam_max = 0;
+                    for (int k = 0; k < q.n; ++k) if (q.cam_off[k + 1] > q.cam_off[k]) cam_max = std::max(cam_max, q.cam_ids[q.cam_off[k + 1] - 1]);
+                    sq.bm_words = cam_max < 65536u ? (int)(cam_max / 32u) + 1 : 0;
+                }
+            }
+        };
+        const int nt = std::max(1, std::min(8, nq / 8));
+        std::vector<std::thread> pool;
+        for (int t = 1; t < nt; ++t) pool.emplace_back(pack);
+        pack();
+        for (std::thread &t : pool) t.join();
+    }
+    if (bad_geometry.load()) return fail(ctx, POSE_AMD_EINVAL, "coverage: image wider than 393216 px");
+    for (int i = 0; i < nq; ++i) {
+        size_t lds = 0;
+        int br, bn, wp, sep;
+        coverage_geometry(queries[i].width, queries[i].height, br, bn, wp, sep, lds);
+        lds_cov = std::max(lds_cov, lds);
+        bands_max = std::max(bands_max, qt[i].bands);
+        bm_max = std::max(bm_max, qt[i].bm_words);
+    }
+    HIPCHK(ctx, hipMemcpyAsync(ctx->sg_qpack.p, ctx->sgh_qpack.p, total, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->sg_qtab.p, ctx->sgh_qtab.p, (size_t)nq * sizeof(seg_query), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(ctx->sg_state.p, 0, (size_t)nq * 33 * 8, ctx->stream));
+
+    // ---- group helpers ------------------------------------------------------------------------------
+    // room per query and round for count records / candidates of the selection; a query that needs more
+    // takes the per-query path (POSE_AMD_SEG_CAPS="records,candidates" shrinks them, for tests of that route)
+    int cap1 = 512, cap2 = 4096;
+    if (const char *e = getenv("POSE_AMD_SEG_CAPS")) {
+        int a1 = 0, a2 = 0;
+        if (sscanf(e, "%d,%d", &a1, &a2) == 2 && a1 > 0 && a2 > 0) { cap1 = std::min(a1, cap1); cap2 = std::min(a2, cap2); }
+    }
+    int *h_active = nullptr;
+    auto upload_active = [&](const std::vector<int> &idx) -> int {
+        int r;
+        if ((r = ensure(ctx, ctx->sg_active, idx.size() * 4)) || (r = ensure_pinned(ctx, ctx->sgh_active, idx.size() * 4))) return r;
+        // the previous group's copy of the list has been consumed: every group ends with a synchronised download or runs on the same stream
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        h_active = (int *)ctx->sgh_active.p;
+        memcpy(h_active, idx.data(), idx.size() * 4);
+        HIPCHK(ctx, hipMemcpyAsync(ctx->sg_active.p, h_active, idx.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+        return POSE_AMD_OK;
+    };
+    std::vector<int64_t> area_all((size_t)nq, 0);
+    {   // all-matches areas (query_processor.cpp:154-169), groups of up to 1024 queries
+        std::vector<int> all;
+        for (int i = 0; i < nq; ++i) if (qi[(size_t)i].live) all.push_back(i);
+        for (size_t g0 = 0; g0 < all.size(); g0 += 1024) {
+            std::vector<int> idx(all.begin() + g0, all.begin() + std::min(all.size(), g0 + 1024));
+            if ((rc = upload_active(idx))) return rc;
+            const size_t nb = idx.size() * bands_max * 8;
+            if ((rc = ensure(ctx, ctx->sg_allsums, nb)) || (rc = ensure_pinned(ctx, ctx->sgh_allsums, nb))) return rc;
+            seg_launch L{(const seg_query *)ctx->sg_qtab.p, (const int *)ctx->sg_active.p, 0, 0, 0};
+            hipLaunchKernelGGL(k_seg_coverage_all, dim3(1, bands_max, (unsigned)idx.size()), dim3(256), lds_cov, ctx->stream, L, (unsigned long long *)ctx->sg_allsums.p,
+                               bands_max);
+            HIPCHK(ctx, hipGetLastError());
+            if ((rc = download(ctx, ctx->sgh_allsums.p, ctx->sg_allsums.p, nb)) || (rc = pose_amd_synchronize(ctx))) return rc;
+            const unsigned long long *sums = (const unsigned long long *)ctx->sgh_allsums.p;
+            for (size_t a = 0; a < idx.size(); ++a)
+                for (int b = 0; b < qt[idx[a]].bands; ++b) area_all[(size_t)idx[a]] += (int64_t)sums[a * bands_max + b];
+        }
+    }
+
+    // ---- rounds ---------------------------------------------------------------------------------------
+    std::vector<char> done((size_t)nq, 0);
+    std::vector<uint32_t> steps_used((size_t)nq, 0);
+    uint32_t step0 = 0, next_len = early ? 1024u : 16384u;
+    const size_t max_slots = (size_t)6 << 20;                // pose slots per launch sequence (about 2 GB of pose data)
+    while (step0 < budget) {
+        const uint32_t valid = std::min(next_len, budget - step0);
+        const int S = (int)((valid + 63) / 64 * 64);
+        bool any = false;
+        for (int solver = 0; solver < 2; ++solver) {
+            const int maxsol = solver ? P4PF_MAXSOL : P3P_MAXSOL;
+            std::vector<int> act;
+            for (int i = 0; i < nq; ++i)
+                if (qi[(size_t)i].live && !done[(size_t)i] && !fallback[(size_t)i] && qi[(size_t)i].maxsol == maxsol) act.push_back(i);
+            const size_t per_group = std::max<size_t>(1, max_slots / ((size_t)S * maxsol));
+            for (size_t g0 = 0; g0 < act.size(); g0 += per_group) {
+                std::vector<int> idx(act.begin() + g0, act.begin() + std::min(act.size(), g0 + per_group));
+                const size_t na = idx.size(), nh = na * S, ns = nh * maxsol;
+                any = true;
+                if ((rc = upload_active(idx))) return rc;
+                if ((rc = ensure(ctx, ctx->sg_samples, nh * 16)) || (rc = ensure(ctx, ctx->sg_sstatus, nh * 4)) || (rc = ensure(ctx, ctx->sg_proj, ns * 96)) ||
+                    (rc = ensure(ctx, ctx->sg_pose, ns * 104)) || (rc = ensure(ctx, ctx->sg_projf, ns * 128)) || (rc = ensure(ctx, ctx->sg_nsol, nh * 4)) ||
+                    (rc = ensure(ctx, ctx->sg_counts, ns * 4)) || (rc = ensure(ctx, ctx->sg_n, na * 8)) || (rc = ensure(ctx, ctx->sg_list1, na * cap1 * 4)) ||
+                    (rc = ensure(ctx, ctx->sg_area1, na * cap1 * 16)) || (rc = ensure(ctx, ctx->sg_bands1, na * cap1 * bands_max * 8)) ||
+                    (rc = ensure(ctx, ctx->sg_list2, na * cap2 * 4)) || (rc = ensure(ctx, ctx->sg_bands2, na * cap2 * bands_max * 8)) ||
+                    (rc = ensure(ctx, ctx->sg_mslot, na * (cap1 + cap2) * 4)) || (rc = ensure(ctx, ctx->sg_marea, na * (cap1 + cap2) * 8)) ||
+                    (rc = ensure(ctx, ctx->sg_mkeep, na * (cap1 + cap2))))
+                    return rc;
+                if (solver && ((rc = ensure(ctx, ctx->sg_arows, nh * P4PF_TAIL * 8)) || (rc = ensure(ctx, ctx->sg_pstatus, nh * 4)))) return rc;
+                seg_launch L{(const seg_query *)ctx->sg_qtab.p, (const int *)ctx->sg_active.p, S, (int)valid, step0};
+                uint32_t *samples = (uint32_t *)ctx->sg_samples.p;
+                double *proj = (double *)ctx->sg_proj.p, *pose = (double *)ctx->sg_pose.p;
+                float *projf = (float *)ctx->sg_projf.p;
+                int *nsol = (int *)ctx->sg_nsol.p, *counts = (int *)ctx->sg_counts.p;
+                if (advanced)
+                    hipLaunchKernelGGL(k_seg_sample_advanced, dim3(cdiv(valid, SAMPLE_ADV_WAVES), (unsigned)na), dim3(64 * SAMPLE_ADV_WAVES),
+                                       (size_t)SAMPLE_ADV_WAVES * std::max(bm_max, 1) * 4, ctx->stream, L, seed, (const double *)ctx->gain.p, samples,
+                                       (int *)ctx->sg_sstatus.p, std::max(bm_max, 1));
+                else
+                    hipLaunchKernelGGL(k_seg_sample_basic, dim3(cdiv(valid, 256), (unsigned)na), dim3(256), 0, ctx->stream, L, seed, samples);
+                if (solver) {
+                    // batch size as in launch_p4pf: 32 systems per block unless that leaves wave slots of the chip empty
+                    const int wslots = (ctx->cus ? ctx->cus : 256) * 8;
+                    const int batch = std::max(4, std::min(4 * cdiv(cdiv((long long)na * valid, wslots), 4), ELIM_BATCH));
+                    hipLaunchKernelGGL(k_seg_p4pf_elim, dim3(cdiv(valid, batch), (unsigned)na), dim3(64), 0, ctx->stream, L, (const uint32_t *)samples,
+                                       (double *)ctx->sg_arows.p, (int *)ctx->sg_pstatus.p, batch);
+                    hipLaunchKernelGGL(k_seg_p4pf_finish, dim3(cdiv(valid, 64), (unsigned)na), dim3(64), 0, ctx->stream, L, (const uint32_t *)samples,
+                                       (const double *)ctx->sg_arows.p, (const int *)ctx->sg_pstatus.p, proj, pose, nsol, projf, prm->eps);
+                } else {
+                    hipLaunchKernelGGL(k_seg_solve_p3p, dim3(cdiv(valid, 64), (unsigned)na), dim3(64), 0, ctx->stream, L, (const uint32_t *)samples, proj, pose, nsol, projf,
+                                       prm->eps);
+                }
+                // slots per block as in launch_score: as many as possible while the launch keeps about four blocks per compute unit
+                int spb = SCORE_SPB;
+                while (spb > 8 && (long long)na * cdiv((long long)valid * maxsol, spb) < (ctx->cus ? ctx->cus : 256) * 4) spb >>= 1;
+                hipLaunchKernelGGL(k_seg_score_screen, dim3(cdiv((long long)valid * maxsol, spb), (unsigned)na), dim3(SCORE_THREADS), 0, ctx->stream, L, maxsol,
+                                   (const double *)proj, (const float *)projf, (const int *)nsol, prm->eps, counts, spb);
+                seg_cov C{(unsigned long long *)ctx->sg_state.p, (int *)ctx->sg_n.p, (int *)ctx->sg_list1.p, (long long *)ctx->sg_area1.p,
+                          (unsigned long long *)ctx->sg_bands1.p, cap1, (int *)ctx->sg_list2.p, (unsigned long long *)ctx->sg_bands2.p, cap2,
+                          (int *)ctx->sg_mslot.p, (long long *)ctx->sg_marea.p, (unsigned char *)ctx->sg_mkeep.p, bands_max};
+                hipLaunchKernelGGL(k_seg_cov_records, dim3((unsigned)na), dim3(COVSEL_THREADS), 0, ctx->stream, L, C, (const int *)counts, (const int *)nsol);
+                hipLaunchKernelGGL(k_seg_coverage, dim3(2, bands_max, (unsigned)na), dim3(256), lds_cov, ctx->stream, L, C, 0, (const double *)proj, prm->eps);
+                hipLaunchKernelGGL(k_seg_cov_candidates, dim3((unsigned)na), dim3(COVSEL_THREADS), 0, ctx->stream, L, C, (const int *)counts, (const int *)nsol);
+                hipLaunchKernelGGL(k_seg_coverage, dim3(8, bands_max, (unsigned)na), dim3(256), lds_cov, ctx->stream, L, C, 1, (const double *)proj, prm->eps);
+                hipLaunchKernelGGL(k_seg_cov_final, dim3((unsigned)na), dim3(COVSEL_THREADS), 0, ctx->stream, L, C, early ? 1 : 0, (const int *)counts,
+                                   (const int *)nsol, (const double *)pose, (const double *)proj);
+                HIPCHK(ctx, hipGetLastError());
+            }
+        }
+        if (!any) break;
+        // ---- outcome of the round ------------------------------------------------------------------------
+        if ((rc = download(ctx, ctx->sgh_state.p, ctx->sg_state.p, (size_t)nq * 33 * 8)) || (rc = pose_amd_synchronize(ctx))) return rc;
+        const unsigned long long *st = (const unsigned long long *)ctx->sgh_state.p;
+        bool more = false;
+        for (int i = 0; i < nq; ++i) {
+            if (!qi[(size_t)i].live || done[(size_t)i] || fallback[(size_t)i]) continue;
+            const unsigned long long *w = st + (size_t)i * 33;
+            if (w[7]) { fallback[(size_t)i] = 1; continue; }
+            pose_amd_result &r = results[i];
+            const int maxsol = qi[(size_t)i].maxsol;
+            steps_used[(size_t)i] += (uint32_t)w[3];
+            r.poses_scored += w[4];
+            if (w[6] != ~0ull) {
+                const double *pz = (const double *)(w + 8);
+                r.found = 1;
+                r.focal = pz[0];
+                memcpy(r.C, pz + 1, 24);
+                memcpy(r.Rc, pz + 4, 72);
+                r.inliers = (uint32_t)w[1];
+                r.area_fit = (int64_t)w[0];
+                r.best_hyp = step0 + (uint32_t)(w[6] / (unsigned)maxsol);
+                r.best_sol = (uint32_t)(w[6] % (unsigned)maxsol);
+            }
+            if (w[5] || step0 + valid >= budget) done[(size_t)i] = 1;
+            // the loop condition at the start of the next step (basic.cpp:132-133) with the pose kept so far
+            else if (early && r.found && r.inliers >= qt[i].thresh) done[(size_t)i] = 1;
+            else more = true;
+        }
+        step0 += valid;
+        next_len = std::min<uint32_t>(16384u, next_len * 4);
+        if (!more) break;
+    }
+    for (int i = 0; i < nq; ++i) {
+        if (fallback[(size_t)i]) continue;
+        results[i].steps = steps_used[(size_t)i];
+        results[i].area_all = qi[(size_t)i].live ? area_all[(size_t)i] : 0;
+    }
+    return POSE_AMD_OK;
+}
+
 // ---- many queries -------------------------------------------------------------------------------
 // Queries are independent (benchmark.cpp:24-36 has no state across iterations).  A few worker
 // threads, each owning a child context (its own stream and buffers), take queries from a shared
@@ -1103,6 +1415,46 @@ int pose_amd_ransac_batch(pose_amd_ctx *ctx, int nq, const pose_amd_query *queri
     if (!ctx || nq < 0 || (nq && (!queries || !results)) || !prm) return fail(ctx, POSE_AMD_EINVAL, "ransac_batch: bad argument");
     if (nq == 0) return POSE_AMD_OK;
     HIPCHK(ctx, hipSetDevice(ctx->device));
+    // The reference's selection (coverage quality) runs many queries per launch; queries that do not
+    // fit that path, and inlier-count selection, take one launch sequence per query on worker threads.
+    static const bool seg_off = getenv("POSE_AMD_BATCH") && strcmp(getenv("POSE_AMD_BATCH"), "threads") == 0;
+    std::vector<char> fallback;
+    std::vector<pose_amd_query> fb_queries;
+    std::vector<int> fb_index;
+    if (!seg_off && prm->select_mode == POSE_AMD_SELECT_COVERAGE && prm->eps > 0 && prm->inlier_divisor != 0 &&
+        (sample_mode == POSE_AMD_SAMPLE_BASIC || sample_mode == POSE_AMD_SAMPLE_ADVANCED)) {
+        const int rc = ransac_batch_segmented(ctx, nq, queries, sample_mode, seed, budget, prm, results, fallback);
+        if (rc) return rc;
+        for (int i = 0; i < nq; ++i) if (fallback[(size_t)i]) { fb_queries.push_back(queries[i]); fb_index.push_back(i); }
+        if (fb_queries.empty()) return POSE_AMD_OK;
+        std::vector<pose_amd_result> fb_results(fb_queries.size());
+        const pose_amd_params p2 = *prm;
+        // the leftover queries, one launch sequence each
+        int rc2 = POSE_AMD_OK;
+        {
+            pose_amd_ctx *l = nullptr;
+            if (ctx->lanes.empty()) {
+                if (pose_amd_create(ctx->device, &l) != POSE_AMD_OK) return fail(ctx, POSE_AMD_EHIP, "ransac_batch: cannot create an internal stream");
+                l->timing = false;
+                l->lazy_sync = true;
+                ctx->lanes.push_back(l);
+            }
+            l = ctx->lanes[0];
+            const bool lazy = l->lazy_sync;
+            l->lazy_sync = false;
+            for (size_t k = 0; k < fb_queries.size() && !rc2; ++k) {
+                const pose_amd_query &q = fb_queries[k];
+                rc2 = pose_amd_set_query(l, q.n, q.kx, q.ky, q.X, q.Y, q.Z, q.lindex, q.width, q.height, q.focal);
+                if (!rc2 && sample_mode == POSE_AMD_SAMPLE_ADVANCED) rc2 = pose_amd_set_camsets(l, q.cam_off, q.cam_ids);
+                if (!rc2) rc2 = pose_amd_sample(l, sample_mode, seed, q.query_id, 0, budget, nullptr);
+                if (!rc2) rc2 = pose_amd_ransac_run(l, &p2, &fb_results[k], nullptr, nullptr);
+                if (rc2) ctx->err = "ransac_batch: query " + std::to_string(fb_index[k]) + ": " + l->err;
+                else results[fb_index[k]] = fb_results[k];
+            }
+            l->lazy_sync = lazy;
+        }
+        return rc2;
+    }
     int nl = 8;
     if (const char *e = getenv("POSE_AMD_BATCH_LANES")) nl = std::max(1, std::min(64, atoi(e)));
     nl = std::min(nl, nq);

@@ -240,6 +240,85 @@ def test_eigen_step_root_sets_on_benchmark_stream(ctx, record_property):
     assert rates["on_stable_tuples"] < 0.01, rates
 
 
+# ---- the multi-query entry point against the per-query sequence ----------------------------------------
+RESULT_KEYS = ("found", "inliers", "steps", "best_hyp", "best_sol", "poses_scored", "area_fit", "area_all")
+
+
+def per_query_sequence(ctx, q, sample_mode, seed, budget, early):
+    ctx.set_query(*oracle_args(q), lindex=q.get("lindex"))
+    if sample_mode == SAMPLE_ADVANCED:
+        ctx.set_camsets(q["cam_off"], q["cam_ids"])
+    ctx.sample(sample_mode, seed, q["query_id"], 0, budget, export=False)
+    return ctx.ransac_run(select_mode=SELECT_COVERAGE, early_exit=early)
+
+
+def mixed_queries():
+    """Known and unknown focal lengths, image shapes whose coverage map does and does not fit the
+    row-union kernel, one query of nine matches, one whose inliers are too few to end the loop in
+    the first round of 1 024 steps, and one with a shared-keypoint index."""
+    spec = [(900, 0.3, False, 1600, 1200), (700, 0.5, True, 1200, 800), (1500, 0.05, False, 1600, 1066), (64, 0.9, True, 640, 480),
+            (9, 1.0, False, 1600, 1200), (1200, 0.2, True, 486, 648), (2500, 0.04, False, 1024, 768), (500, 0.4, True, 1600, 1064),
+            (1100, 0.15, False, 1066, 1600), (3000, 0.03, True, 1600, 1200)]
+    out = []
+    for i, (n, frac, known, w, h) in enumerate(spec):
+        q = synth.make_query(n, frac, 900 + i, width=w, height=h, known_focal=known)
+        synth.add_camsets(q, 900 + i)
+        if n < 100:                                  # too few matches for the 3 % with five or more cameras: give every match six
+            ids = np.sort(np.random.default_rng(i).choice(q["cam_common"], (n, 6), replace=True), axis=1)
+            ids += np.arange(6) * 7000               # strictly increasing per set
+            q["cam_off"], q["cam_ids"] = (6 * np.arange(n + 1)).astype(np.uint32), ids.reshape(-1).astype(np.uint32)
+        q["query_id"] = 40 + 3 * i
+        out.append(q)
+    out[3]["lindex"] = (np.arange(64, dtype=np.uint32) // 2).astype(np.uint32)
+    return out
+
+
+@pytest.mark.parametrize("sample_mode,budget,early", [(SAMPLE_BASIC, 2500, True), (SAMPLE_BASIC, 1500, False), (SAMPLE_ADVANCED, 100, False),
+                                                       (SAMPLE_ADVANCED, 1100, True)])
+def test_multi_query_launches_equal_the_per_query_sequence(ctx, sample_mode, budget, early):
+    """pose_amd_ransac_batch with the reference's selection runs all queries of a batch in shared
+    launches (rounds of 1 024, 4 096, ... steps).  Every field of every result, the pose included,
+    is bit-identical to set_query + (set_camsets) + sample + ransac_run on that query alone."""
+    queries = mixed_queries()
+    got = ctx.ransac_batch(queries, sample_mode, seed=5, budget=budget, select_mode=SELECT_COVERAGE, early_exit=early)
+    rounds = set()
+    for q, g in zip(queries, got):
+        o = per_query_sequence(ctx, q, sample_mode, 5, budget, early)
+        for k in RESULT_KEYS:
+            assert g[k] == o[k], (k, len(q["kx"]), g[k], o[k])
+        assert np.array_equal(g["C"], o["C"]) and np.array_equal(g["Rc"], o["Rc"]) and g["focal"] == o["focal"]
+        rounds.add(0 if g["steps"] <= 1024 else 1 if g["steps"] <= 5120 else 2)
+    if early and budget > 1024:
+        assert len(rounds) >= 2, rounds              # some queries end in the first round, some need the second
+
+
+def test_multi_query_launches_hand_crowded_queries_to_the_per_query_path(ctx, monkeypatch):
+    """A query with more count records or candidates in a round than the shared launch has room
+    for is finished by the per-query path instead; with the room shrunk to 2 records / 3 candidates
+    that is most queries, and the results do not change."""
+    queries = mixed_queries()
+    want = ctx.ransac_batch(queries, SAMPLE_BASIC, seed=8, budget=1500, select_mode=SELECT_COVERAGE, early_exit=True)
+    monkeypatch.setenv("POSE_AMD_SEG_CAPS", "2,3")
+    got = ctx.ransac_batch(queries, SAMPLE_BASIC, seed=8, budget=1500, select_mode=SELECT_COVERAGE, early_exit=True)
+    for a, b in zip(want, got):
+        for k in RESULT_KEYS:
+            assert a[k] == b[k], k
+        assert np.array_equal(a["C"], b["C"]) and np.array_equal(a["Rc"], b["Rc"]) and a["focal"] == b["focal"]
+
+
+def test_multi_query_launches_report_bad_queries(ctx):
+    queries = mixed_queries()[:3]
+    bad = dict(queries[1]); bad["kx"] = bad["kx"][:2]; bad["ky"] = bad["ky"][:2]; bad["X"] = bad["X"][:2]; bad["Y"] = bad["Y"][:2]; bad["Z"] = bad["Z"][:2]
+    bad.pop("cam_off"); bad.pop("cam_ids")
+    with pytest.raises(Exception, match="query 1"):
+        ctx.ransac_batch([queries[0], bad, queries[2]], SAMPLE_BASIC, seed=8, budget=100, select_mode=SELECT_COVERAGE, early_exit=True)
+    with pytest.raises(Exception, match="query 1"):
+        ctx.ransac_batch([queries[0], bad, queries[2]], SAMPLE_ADVANCED, seed=8, budget=100, select_mode=SELECT_COVERAGE, early_exit=True)
+    assert ctx.ransac_batch([], SAMPLE_BASIC, seed=8, budget=100) == []
+    zero = ctx.ransac_batch(queries, SAMPLE_BASIC, seed=8, budget=0, select_mode=SELECT_COVERAGE, early_exit=True)
+    assert all(z["found"] == 0 and z["steps"] == 0 for z in zero)
+
+
 # ---- several devices / ranks through the C ABI -----------------------------------------------------------
 def test_batch_over_a_device_list_equals_the_single_device_batch(ctx):
     """pose_amd_ransac_batch_multi with device 0 listed twice (two contexts, two host threads, the
