@@ -102,12 +102,12 @@ __global__ __launch_bounds__(SCORE_THREADS) __attribute__((amdgpu_waves_per_eu(6
 }
 
 // ---- coverage-quality selection, one block per query -----------------------------------------------
-// Per-query scratch of the selection (positions in the group): state 33 words, n 2 ints,
+// Per-query scratch of the selection (positions in the group): state 33 words, n 4 ints,
 // list1 / area1 / bands1 for cap1 records, list2 / bands2 for cap2 candidates, merge scratch
 // for cap1 + cap2 entries.
 struct seg_cov {
     unsigned long long *state;   // [queries of the batch][33], indexed by query (carried over rounds)
-    int *n;                      // [group][2]
+    int *n;                      // [group][4]: records, candidates, slot limit of the replay, records below it
     int *list1; long long *area1; unsigned long long *bands1; int cap1;
     int *list2; unsigned long long *bands2; int cap2;
     int *mslot; long long *marea; unsigned char *mkeep;
@@ -122,7 +122,7 @@ __global__ __launch_bounds__(COVSEL_THREADS) void k_seg_cov_records(seg_launch L
     const seg_query &sq = seg_of(L, a);
     const size_t base = (size_t)a * L.S;
     cov_records_block(L.V * sq.maxsol, counts + base * sq.maxsol, nsol + base, sq.maxsol, sq.box, C.state + (size_t)L.active[a] * 33,
-                      C.list1 + (size_t)a * C.cap1, C.n + 2 * a, C.cap1, s_tmp);
+                      C.list1 + (size_t)a * C.cap1, C.n + 4 * a, C.cap1, s_tmp);
 }
 
 // which = 0: the records (list1), 1: the candidates (list2); blockIdx.z = position in the group.
@@ -136,7 +136,7 @@ __global__ __launch_bounds__(256) void k_seg_coverage(seg_launch L, seg_cov C, i
     const seg_query &sq = seg_of(L, a);
     if ((int)blockIdx.y >= sq.bands) return;
     const int cap = which ? C.cap2 : C.cap1;
-    const int n = min(C.n[2 * a + which], cap);
+    const int n = min(C.n[4 * a + which], cap);
     const int *list = which ? C.list2 + (size_t)a * C.cap2 : C.list1 + (size_t)a * C.cap1;
     unsigned long long *sums = which ? C.bands2 + (size_t)a * C.cap2 * C.bands_max : C.bands1 + (size_t)a * C.cap1 * C.bands_max;
     const double *pq = proj + (size_t)a * L.S * sq.maxsol * 12;
@@ -162,24 +162,26 @@ __global__ __launch_bounds__(256) void k_seg_coverage_all(seg_launch L, unsigned
     else coverage_band_direct(sq.q, 0, nullptr, nullptr, 0.5, 1, sq.band_rows, sq.wpr, out, s_bm, s_sum, blockIdx.y, 1);
 }
 
-__global__ __launch_bounds__(COVSEL_THREADS) void k_seg_cov_candidates(seg_launch L, seg_cov C, const int *__restrict__ counts,
+__global__ __launch_bounds__(COVSEL_THREADS) void k_seg_cov_candidates(seg_launch L, seg_cov C, int early_exit, const int *__restrict__ counts,
                                                                         const int *__restrict__ nsol)
 {
     __shared__ int s_tmp[COVSEL_THREADS / 64];
+    __shared__ int s_limit;
     const int a = blockIdx.x;
     const seg_query &sq = seg_of(L, a);
     const size_t base = (size_t)a * L.S;
-    if (C.n[2 * a] > C.cap1) {                           // truncated record list (block-uniform): k_seg_cov_final reports it
-        if (threadIdx.x == 0) C.n[2 * a + 1] = 0;
+    if (C.n[4 * a] > C.cap1) {                           // truncated record list (block-uniform): k_seg_cov_final reports it
+        if (threadIdx.x == 0) C.n[4 * a + 1] = 0;
         return;
     }
     cov_candidates_block(L.V * sq.maxsol, counts + base * sq.maxsol, nsol + base, sq.maxsol, sq.box, C.state + (size_t)L.active[a] * 33,
-                         C.list1 + (size_t)a * C.cap1, C.n + 2 * a, C.bands1 + (size_t)a * C.cap1 * C.bands_max, sq.bands,
-                         C.area1 + (size_t)a * 2 * C.cap1, C.list2 + (size_t)a * C.cap2, C.n + 2 * a + 1, C.cap2, s_tmp);
+                         C.list1 + (size_t)a * C.cap1, C.n + 4 * a, C.bands1 + (size_t)a * C.cap1 * C.bands_max, sq.bands,
+                         C.area1 + (size_t)a * 2 * C.cap1, C.list2 + (size_t)a * C.cap2, C.cap2, sq.thresh, early_exit, s_tmp, s_limit);
 }
 
-// state word 7 is set to 1 when the query had more candidates than the launch has room for: the
-// caller then runs that query through the per-query path instead.
+// state word 7 is set to 1 when the query had more candidates than the launch has room for (or the
+// shortened replay did not end the loop): the caller then runs that query through the per-query
+// path instead.
 __global__ __launch_bounds__(COVSEL_THREADS) void k_seg_cov_final(seg_launch L, seg_cov C, int early_exit, const int *__restrict__ counts,
                                                                    const int *__restrict__ nsol, const double *__restrict__ pose,
                                                                    const double *__restrict__ proj)
@@ -189,12 +191,12 @@ __global__ __launch_bounds__(COVSEL_THREADS) void k_seg_cov_final(seg_launch L, 
     const seg_query &sq = seg_of(L, a);
     const size_t base = (size_t)a * L.S, sbase = base * sq.maxsol;
     unsigned long long *state = C.state + (size_t)L.active[a] * 33;
-    if (C.n[2 * a] > C.cap1 || C.n[2 * a + 1] > C.cap2) {   // block-uniform
+    if (C.n[4 * a] > C.cap1 || C.n[4 * a + 1] > C.cap2) {   // block-uniform
         if (threadIdx.x == 0) state[7] = 1ull;
         return;
     }
     cov_final_block(L.V * sq.maxsol, L.V, counts + sbase, nsol + base, sq.maxsol, sq.thresh, early_exit, C.list1 + (size_t)a * C.cap1,
-                    C.n + 2 * a, C.area1 + (size_t)a * 2 * C.cap1, C.list2 + (size_t)a * C.cap2, C.n + 2 * a + 1,
+                    C.n + 4 * a, C.area1 + (size_t)a * 2 * C.cap1, C.list2 + (size_t)a * C.cap2,
                     C.bands2 + (size_t)a * C.cap2 * C.bands_max, sq.bands, C.mslot + (size_t)a * (C.cap1 + C.cap2), C.marea + (size_t)a * (C.cap1 + C.cap2),
                     C.mkeep + (size_t)a * (C.cap1 + C.cap2), pose + sbase * 13, proj + sbase * 12, state, lds);
 }

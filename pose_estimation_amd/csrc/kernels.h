@@ -1121,8 +1121,17 @@ __global__ __launch_bounds__(256) void k_coverage_direct(query_dev q, int nposes
 //                    pose, the step the loop ends at, the number of poses scored until then
 // state (unsigned long long words): [0] best area, [1] best count, [2] 1 if a pose has been kept,
 //   [3] steps used in the chunk, [4] poses scored in the chunk, [5] 1 if the loop ended inside
-//   the chunk, [6] slot of the pose kept in THIS chunk or ~0, [7] unused, [8..20] its pose record,
+//   the chunk, [6] slot of the pose kept in THIS chunk or ~0, [7] 1 if the chunk's selection must
+//   be repeated (see below; nothing else is written then), [8..20] its pose record,
 //   [21..32] its projection matrix.  Words 0..2 carry over from chunk to chunk.
+// With early exit the loop usually ends at the first pose with >= thresh inliers, long before the
+// chunk does, and nothing behind that step matters.  k_cov_candidates therefore looks for the first
+// count record r with >= thresh inliers whose exact area beats every area before it for certain
+// (the area carried in and box * the count of the record before r bound them): r is kept, the loop
+// ends with r's step unless a later solution of that step with < thresh inliers replaces it, and
+// candidates are only listed up to the end of that step (n[2] = that slot limit, n[3] = records
+// below it).  In the rare case that the replay over the shortened range finds no end of the loop,
+// k_cov_final sets state word 7 and the caller repeats candidates + replay with limit_ok = 0.
 // ------------------------------------------------------------------------------------------
 constexpr int COVSEL_THREADS = 256;
 
@@ -1215,14 +1224,16 @@ __device__ __forceinline__ int covsel_lower_bound(const int *__restrict__ a, int
 
 // list2 holds at most cap2 entries; *n2 gets the number found (beyond cap2: the list is truncated
 // and the caller must not use it).
-__device__ __forceinline__ void cov_candidates_block(int nslots, const int *__restrict__ counts, const int *__restrict__ nsol, int maxsol,
+__device__ __forceinline__ void cov_candidates_block(int nslots_all, const int *__restrict__ counts, const int *__restrict__ nsol, int maxsol,
                                                      long long box, const unsigned long long *__restrict__ state,
-                                                     const int *__restrict__ list1, const int *__restrict__ n1p,
+                                                     const int *__restrict__ list1, int *__restrict__ nn,
                                                      const unsigned long long *__restrict__ bands1, int nbands,
-                                                     long long *__restrict__ area1, int *__restrict__ list2, int *__restrict__ n2, int cap2, int *s_tmp)
+                                                     long long *__restrict__ area1, int *__restrict__ list2, int cap2,
+                                                     unsigned int thresh, int limit_ok, int *s_tmp, int &s_limit)
 {
     const int tid = threadIdx.x;
-    const int n1 = *n1p;
+    const int n1 = nn[0];
+    int *n2 = nn + 1;
     const long long carried = (long long)state[0];
     // exact areas of the records, then their running maximum in slot order (the list is in slot
     // order and short -- counts rise strictly along it -- so one thread does the prefix pass)
@@ -1231,8 +1242,23 @@ __device__ __forceinline__ void cov_candidates_block(int nslots, const int *__re
     if (tid == 0) {
         long long m = carried;
         for (int i = 0; i < n1; ++i) { m = max(m, area1[i]); area1[n1 + i] = m; }      // area1[n1 + i]: best area after record i
+        // the first record that is kept for certain and ends the loop
+        int limit = nslots_all, n1_eff = n1;
+        if (limit_ok) {
+            long long before = carried;                  // bound of every area before record i
+            for (int i = 0; i < n1; ++i) {
+                const int c = counts[list1[i]];
+                if ((unsigned int)c >= thresh && area1[i] > before) { limit = (list1[i] / maxsol + 1) * maxsol; break; }
+                before = max(before, (long long)c * box);
+            }
+            limit = min(limit, nslots_all);
+            n1_eff = covsel_lower_bound(list1, n1, limit);
+        }
+        nn[2] = limit; nn[3] = n1_eff;
+        s_limit = limit;
     }
     __syncthreads();
+    const int nslots = s_limit;
     int n = 0;
     for (int base = 0; base < nslots; base += COVSEL_THREADS * COVSEL_K) {
         unsigned flags = 0;
@@ -1263,12 +1289,13 @@ __device__ __forceinline__ void cov_candidates_block(int nslots, const int *__re
 
 __global__ __launch_bounds__(COVSEL_THREADS) void k_cov_candidates(int nslots, const int *__restrict__ counts, const int *__restrict__ nsol, int maxsol,
                                                                     long long box, const unsigned long long *__restrict__ state,
-                                                                    const int *__restrict__ list1, const int *__restrict__ n1p,
+                                                                    const int *__restrict__ list1, int *__restrict__ nn,
                                                                     const unsigned long long *__restrict__ bands1, int nbands,
-                                                                    long long *__restrict__ area1, int *__restrict__ list2, int *__restrict__ n2)
+                                                                    long long *__restrict__ area1, int *__restrict__ list2, unsigned int thresh, int limit_ok)
 {
     __shared__ int s_tmp[COVSEL_THREADS / 64];
-    cov_candidates_block(nslots, counts, nsol, maxsol, box, state, list1, n1p, bands1, nbands, area1, list2, n2, nslots, s_tmp);
+    __shared__ int s_limit;
+    cov_candidates_block(nslots, counts, nsol, maxsol, box, state, list1, nn, bands1, nbands, area1, list2, nslots, thresh, limit_ok, s_tmp, s_limit);
 }
 
 // Replay in slot order over records + candidates, in parallel: (1) the two lists are merged by
@@ -1284,10 +1311,10 @@ struct cov_final_lds {
     int steps, kept;
 };
 
-__device__ __forceinline__ void cov_final_block(int nslots, int steps_in_chunk, const int *__restrict__ counts, const int *__restrict__ nsol,
+__device__ __forceinline__ void cov_final_block(int nslots_all, int steps_in_chunk, const int *__restrict__ counts, const int *__restrict__ nsol,
                                                 int maxsol, unsigned int thresh, int early_exit, const int *__restrict__ list1,
-                                                const int *__restrict__ n1p, const long long *__restrict__ area1,
-                                                const int *__restrict__ list2, const int *__restrict__ n2p,
+                                                const int *__restrict__ nn, const long long *__restrict__ area1,
+                                                const int *__restrict__ list2,
                                                 const unsigned long long *__restrict__ bands2, int nbands,
                                                 int *__restrict__ mslot, long long *__restrict__ marea, unsigned char *__restrict__ mkeep,
                                                 const double *__restrict__ pose, const double *__restrict__ proj,
@@ -1298,7 +1325,7 @@ __device__ __forceinline__ void cov_final_block(int nslots, int steps_in_chunk, 
     unsigned long long *s_cnt = L.cnt;
     int &s_steps = L.steps, &s_kept = L.kept;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int n1 = *n1p, n2 = *n2p, N = n1 + n2;
+    const int n2 = nn[1], nslots = nn[2], n1 = nn[3], N = n1 + n2;     // records and candidates below the slot limit
     const long long carried = (long long)state[0];
     for (int i = tid; i < n1; i += COVSEL_THREADS) {
         const int pos = i + covsel_lower_bound(list2, n2, list1[i]);
@@ -1345,19 +1372,25 @@ __device__ __forceinline__ void cov_final_block(int nslots, int steps_in_chunk, 
         for (int w2 = 1; w2 < COVSEL_THREADS / 64; ++w2) { exit_idx = min(exit_idx, s_exit[w2]); last_idx = max(last_idx, s_last[w2]); }
         const bool done = exit_idx != 0x7fffffff;
         const int kept = done ? exit_idx : last_idx;             // index in the merged list, -1: nothing kept in this chunk
-        int steps = steps_in_chunk;
-        if (kept >= 0) {
-            const int slot = mslot[kept];
-            state[0] = (unsigned long long)marea[kept]; state[1] = (unsigned long long)(unsigned int)counts[slot]; state[2] = 1ull;
-            state[6] = (unsigned long long)slot;
-            if (done) steps = slot / maxsol + 1;
+        if (!done && nslots < nslots_all) {                      // the shortened range did not end the loop: repeat without the limit
+            state[7] = 1ull;
+            s_steps = -1; s_kept = -1;
         } else {
-            state[6] = ~0ull;
+            int steps = steps_in_chunk;
+            if (kept >= 0) {
+                const int slot = mslot[kept];
+                state[0] = (unsigned long long)marea[kept]; state[1] = (unsigned long long)(unsigned int)counts[slot]; state[2] = 1ull;
+                state[6] = (unsigned long long)slot;
+                if (done) steps = slot / maxsol + 1;
+            } else {
+                state[6] = ~0ull;
+            }
+            state[3] = (unsigned long long)steps; state[5] = done ? 1ull : 0ull; state[7] = 0ull;
+            s_steps = steps; s_kept = kept >= 0 ? mslot[kept] : -1;
         }
-        state[3] = (unsigned long long)steps; state[5] = done ? 1ull : 0ull;
-        s_steps = steps; s_kept = kept >= 0 ? mslot[kept] : -1;
     }
     __syncthreads();
+    if (s_steps < 0) return;                                     // block-uniform
     // poses scored by the loop: the valid slots of the steps it ran
     const int lim = min(s_steps * maxsol, nslots);
     unsigned long long nv = 0;
@@ -1377,15 +1410,15 @@ __device__ __forceinline__ void cov_final_block(int nslots, int steps_in_chunk, 
 
 __global__ __launch_bounds__(COVSEL_THREADS) void k_cov_final(int nslots, int steps_in_chunk, const int *__restrict__ counts, const int *__restrict__ nsol,
                                                                int maxsol, unsigned int thresh, int early_exit, const int *__restrict__ list1,
-                                                               const int *__restrict__ n1p, const long long *__restrict__ area1,
-                                                               const int *__restrict__ list2, const int *__restrict__ n2p,
+                                                               const int *__restrict__ nn, const long long *__restrict__ area1,
+                                                               const int *__restrict__ list2,
                                                                const unsigned long long *__restrict__ bands2, int nbands,
                                                                int *__restrict__ mslot, long long *__restrict__ marea, unsigned char *__restrict__ mkeep,
                                                                const double *__restrict__ pose, const double *__restrict__ proj,
                                                                unsigned long long *__restrict__ state)
 {
     __shared__ cov_final_lds L;
-    cov_final_block(nslots, steps_in_chunk, counts, nsol, maxsol, thresh, early_exit, list1, n1p, area1, list2, n2p, bands2, nbands, mslot, marea, mkeep,
+    cov_final_block(nslots, steps_in_chunk, counts, nsol, maxsol, thresh, early_exit, list1, nn, area1, list2, bands2, nbands, mslot, marea, mkeep,
                     pose, proj, state, L);
 }
 

@@ -736,7 +736,7 @@ static int coverage_select_chunk(pose_amd_ctx *ctx, const pose_amd_params *prm, 
     const int bands = cdiv(ctx->height, band_rows);
     const size_t n1cap = (size_t)std::min(nslots, ctx->n + 1);        // counts rise strictly along the records
     int rc;
-    if ((rc = ensure(ctx, ctx->cov_n, 16)) || (rc = ensure(ctx, ctx->cov_list1, n1cap * 4)) || (rc = ensure(ctx, ctx->cov_bands1, n1cap * bands * 8)) ||
+    if ((rc = ensure(ctx, ctx->cov_n, 32)) || (rc = ensure(ctx, ctx->cov_list1, n1cap * 4)) || (rc = ensure(ctx, ctx->cov_bands1, n1cap * bands * 8)) ||
         (rc = ensure(ctx, ctx->cov_area1, n1cap * 16)) || (rc = ensure(ctx, ctx->cov_list2, (size_t)nslots * 4)) ||
         (rc = ensure(ctx, ctx->cov_bands2, (size_t)nslots * bands * 8)) || (rc = ensure(ctx, ctx->cov_mslot, (n1cap + nslots) * 4)) ||
         (rc = ensure(ctx, ctx->cov_marea, (n1cap + nslots) * 8)) || (rc = ensure(ctx, ctx->cov_mkeep, n1cap + nslots)))
@@ -757,17 +757,22 @@ static int coverage_select_chunk(pose_amd_ctx *ctx, const pose_amd_params *prm, 
     };
     hipLaunchKernelGGL(k_cov_records, dim3(1), dim3(COVSEL_THREADS), 0, ctx->stream, nslots, counts, nsol, maxsol, box, state, (int *)ctx->cov_list1.p, nn);
     cover(32, nn, (const int *)ctx->cov_list1.p, (unsigned long long *)ctx->cov_bands1.p);
-    hipLaunchKernelGGL(k_cov_candidates, dim3(1), dim3(COVSEL_THREADS), 0, ctx->stream, nslots, counts, nsol, maxsol, box, state,
-                       (const int *)ctx->cov_list1.p, nn, (const unsigned long long *)ctx->cov_bands1.p, bands, (long long *)ctx->cov_area1.p,
-                       (int *)ctx->cov_list2.p, nn + 1);
-    cover(128, nn + 1, (const int *)ctx->cov_list2.p, (unsigned long long *)ctx->cov_bands2.p);
-    hipLaunchKernelGGL(k_cov_final, dim3(1), dim3(COVSEL_THREADS), 0, ctx->stream, nslots, steps, counts, nsol, maxsol, thresh, prm->early_exit ? 1 : 0,
-                       (const int *)ctx->cov_list1.p, nn, (const long long *)ctx->cov_area1.p, (const int *)ctx->cov_list2.p, nn + 1,
-                       (const unsigned long long *)ctx->cov_bands2.p, bands, (int *)ctx->cov_mslot.p, (long long *)ctx->cov_marea.p,
-                       (unsigned char *)ctx->cov_mkeep.p, (const double *)ctx->pose.p, proj, state);
-    HIPCHK(ctx, hipGetLastError());
     unsigned long long *host = (unsigned long long *)ctx->h_words.p + 64;
-    if ((rc = download(ctx, host, state, 33 * 8)) || (rc = pose_amd_synchronize(ctx))) return rc;
+    // with early exit the candidates are first listed up to the step that ends the loop for certain;
+    // should the replay over that range not end the loop (word 7), both steps run again over the whole chunk
+    for (int limit_ok = prm->early_exit ? 1 : 0; limit_ok >= 0; --limit_ok) {
+        hipLaunchKernelGGL(k_cov_candidates, dim3(1), dim3(COVSEL_THREADS), 0, ctx->stream, nslots, counts, nsol, maxsol, box, state,
+                           (const int *)ctx->cov_list1.p, nn, (const unsigned long long *)ctx->cov_bands1.p, bands, (long long *)ctx->cov_area1.p,
+                           (int *)ctx->cov_list2.p, thresh, limit_ok);
+        cover(128, nn + 1, (const int *)ctx->cov_list2.p, (unsigned long long *)ctx->cov_bands2.p);
+        hipLaunchKernelGGL(k_cov_final, dim3(1), dim3(COVSEL_THREADS), 0, ctx->stream, nslots, steps, counts, nsol, maxsol, thresh, prm->early_exit ? 1 : 0,
+                           (const int *)ctx->cov_list1.p, nn, (const long long *)ctx->cov_area1.p, (const int *)ctx->cov_list2.p,
+                           (const unsigned long long *)ctx->cov_bands2.p, bands, (int *)ctx->cov_mslot.p, (long long *)ctx->cov_marea.p,
+                           (unsigned char *)ctx->cov_mkeep.p, (const double *)ctx->pose.p, proj, state);
+        HIPCHK(ctx, hipGetLastError());
+        if ((rc = download(ctx, host, state, 33 * 8)) || (rc = pose_amd_synchronize(ctx))) return rc;
+        if (host[7] == 0ull) break;
+    }
     memcpy(out, host, 33 * 8);
     return POSE_AMD_OK;
 }
@@ -1297,7 +1302,14 @@ static int ransac_batch_segmented(pose_amd_ctx *ctx, int nq, const pose_amd_quer
     // ---- rounds ---------------------------------------------------------------------------------------
     std::vector<char> done((size_t)nq, 0);
     std::vector<uint32_t> steps_used((size_t)nq, 0);
-    uint32_t step0 = 0, next_len = early ? 1024u : 16384u;
+    // With early exit most queries end long before the budget does, and every step of a round behind a
+    // query's last one is wasted: rounds start short and double.
+    uint32_t first_len = 64u, growth = 2u;
+    if (const char *e = getenv("POSE_AMD_SEG_ROUNDS")) {
+        unsigned a1 = 0, a2 = 0;
+        if (sscanf(e, "%u,%u", &a1, &a2) == 2 && a1 >= 16 && a2 >= 2) { first_len = std::min(a1, 16384u); growth = std::min(a2, 16u); }
+    }
+    uint32_t step0 = 0, next_len = early ? first_len : 16384u;
     const size_t max_slots = (size_t)6 << 20;                // pose slots per launch sequence (about 2 GB of pose data)
     while (step0 < budget) {
         const uint32_t valid = std::min(next_len, budget - step0);
@@ -1316,7 +1328,7 @@ static int ransac_batch_segmented(pose_amd_ctx *ctx, int nq, const pose_amd_quer
                 if ((rc = upload_active(idx))) return rc;
                 if ((rc = ensure(ctx, ctx->sg_samples, nh * 16)) || (rc = ensure(ctx, ctx->sg_sstatus, nh * 4)) || (rc = ensure(ctx, ctx->sg_proj, ns * 96)) ||
                     (rc = ensure(ctx, ctx->sg_pose, ns * 104)) || (rc = ensure(ctx, ctx->sg_projf, ns * 128)) || (rc = ensure(ctx, ctx->sg_nsol, nh * 4)) ||
-                    (rc = ensure(ctx, ctx->sg_counts, ns * 4)) || (rc = ensure(ctx, ctx->sg_n, na * 8)) || (rc = ensure(ctx, ctx->sg_list1, na * cap1 * 4)) ||
+                    (rc = ensure(ctx, ctx->sg_counts, ns * 4)) || (rc = ensure(ctx, ctx->sg_n, na * 16)) || (rc = ensure(ctx, ctx->sg_list1, na * cap1 * 4)) ||
                     (rc = ensure(ctx, ctx->sg_area1, na * cap1 * 16)) || (rc = ensure(ctx, ctx->sg_bands1, na * cap1 * bands_max * 8)) ||
                     (rc = ensure(ctx, ctx->sg_list2, na * cap2 * 4)) || (rc = ensure(ctx, ctx->sg_bands2, na * cap2 * bands_max * 8)) ||
                     (rc = ensure(ctx, ctx->sg_mslot, na * (cap1 + cap2) * 4)) || (rc = ensure(ctx, ctx->sg_marea, na * (cap1 + cap2) * 8)) ||
@@ -1356,11 +1368,20 @@ static int ransac_batch_segmented(pose_amd_ctx *ctx, int nq, const pose_amd_quer
                           (int *)ctx->sg_mslot.p, (long long *)ctx->sg_marea.p, (unsigned char *)ctx->sg_mkeep.p, bands_max};
                 hipLaunchKernelGGL(k_seg_cov_records, dim3((unsigned)na), dim3(COVSEL_THREADS), 0, ctx->stream, L, C, (const int *)counts, (const int *)nsol);
                 hipLaunchKernelGGL(k_seg_coverage, dim3(2, bands_max, (unsigned)na), dim3(256), lds_cov, ctx->stream, L, C, 0, (const double *)proj, prm->eps);
-                hipLaunchKernelGGL(k_seg_cov_candidates, dim3((unsigned)na), dim3(COVSEL_THREADS), 0, ctx->stream, L, C, (const int *)counts, (const int *)nsol);
+                hipLaunchKernelGGL(k_seg_cov_candidates, dim3((unsigned)na), dim3(COVSEL_THREADS), 0, ctx->stream, L, C, early ? 1 : 0, (const int *)counts,
+                                   (const int *)nsol);
                 hipLaunchKernelGGL(k_seg_coverage, dim3(8, bands_max, (unsigned)na), dim3(256), lds_cov, ctx->stream, L, C, 1, (const double *)proj, prm->eps);
                 hipLaunchKernelGGL(k_seg_cov_final, dim3((unsigned)na), dim3(COVSEL_THREADS), 0, ctx->stream, L, C, early ? 1 : 0, (const int *)counts,
                                    (const int *)nsol, (const double *)pose, (const double *)proj);
                 HIPCHK(ctx, hipGetLastError());
+                if (getenv("POSE_AMD_SEG_STATS")) {          // development aid: list lengths of the group
+                    std::vector<int> nn(na * 4);
+                    HIPCHK(ctx, hipMemcpyAsync(nn.data(), ctx->sg_n.p, na * 16, hipMemcpyDeviceToHost, ctx->stream));
+                    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+                    long long s1 = 0, s2 = 0; int m1 = 0, m2 = 0;
+                    for (size_t a = 0; a < na; ++a) { s1 += nn[4 * a]; s2 += nn[4 * a + 1]; m1 = std::max(m1, nn[4 * a]); m2 = std::max(m2, nn[4 * a + 1]); }
+                    fprintf(stderr, "seg: step0 %u steps %u solver %d queries %zu records %lld (max %d) candidates %lld (max %d)\n", step0, valid, solver, na, s1, m1, s2, m2);
+                }
             }
         }
         if (!any) break;
@@ -1393,7 +1414,7 @@ static int ransac_batch_segmented(pose_amd_ctx *ctx, int nq, const pose_amd_quer
             else more = true;
         }
         step0 += valid;
-        next_len = std::min<uint32_t>(16384u, next_len * 4);
+        next_len = std::min<uint32_t>(16384u, next_len * growth);
         if (!more) break;
     }
     for (int i = 0; i < nq; ++i) {

@@ -292,6 +292,36 @@ def test_multi_query_launches_equal_the_per_query_sequence(ctx, sample_mode, bud
         assert len(rounds) >= 2, rounds              # some queries end in the first round, some need the second
 
 
+def test_multi_query_launches_equal_the_oracle_loop_on_many_small_queries(ctx):
+    """Sixty small queries (200-900 matches, 8-60 % inliers, both solvers, four image shapes)
+    through the shared launches with the reference's loop; steps, kept hypothesis and solution,
+    inliers and both areas equal the oracle's sequential loop on the exported tuples.  Low inlier
+    ratios make many loops end on a chance pose with barely 12 inliers -- the cases where the
+    replay cannot stop at the first count record."""
+    rng = np.random.default_rng(77)
+    shapes = [(1600, 1200), (1200, 1600), (640, 480), (1066, 1600)]
+    queries = []
+    for i in range(60):
+        w, h = shapes[i % 4]
+        q = synth.make_query(int(rng.integers(200, 901)), float(rng.uniform(0.08, 0.6)), 7000 + i, width=w, height=h, known_focal=bool(i & 1))
+        q["query_id"] = i
+        queries.append(q)
+    budget, seed = 1200, 99
+    got = ctx.ransac_batch(queries, SAMPLE_BASIC, seed=seed, budget=budget, select_mode=SELECT_COVERAGE, early_exit=True)
+    ended_early = 0
+    for q, g in zip(queries, got):
+        ctx.set_query(*oracle_args(q))
+        s = ctx.sample(SAMPLE_BASIC, seed, q["query_id"], 0, budget)
+        s[:, 3] = np.where(s[:, 3] == 0xFFFFFFFF, 0, s[:, 3])
+        o = O.ransac(*oracle_args(q), s, select_coverage=True, early_exit=True, max_steps=budget)
+        key = (q["query_id"], len(q["kx"]))
+        assert (g["found"], g["steps"], g["area_all"]) == (o["found"], o["steps"], o["area_all"]), key
+        if o["found"]:
+            assert (g["best_hyp"], g["inliers"], g["area_fit"]) == (o["best_step"], o["hyposet"], o["area_fit"]), key
+        ended_early += g["steps"] < budget
+    assert 20 <= ended_early <= 59, ended_early
+
+
 def test_multi_query_launches_hand_crowded_queries_to_the_per_query_path(ctx, monkeypatch):
     """A query with more count records or candidates in a round than the shared launch has room
     for is finished by the per-query path instead; with the room shrunk to 2 records / 3 candidates

@@ -44,7 +44,7 @@ QUAD_CHUNK = int(os.environ.get("P4PF_ELIM_QUAD_CHUNK", "16"))   # pivot-row ent
 
 
 def load_template():
-    txt = open(os.path.join(ROOT, "oracle", "p4pf_template.h")).read()
+    txt = open(os.path.join(ROOT, "pose_estimation_amd", "csrc", "p4pf_template.h")).read()
     out = {}
     for name in ("ROW", "COL", "COEF"):
         m = re.search(r"P4PF_TPL_%s\[\d+\] = \{([^}]*)\}" % name, txt)
