@@ -65,6 +65,8 @@ def parse_args():
     ap.add_argument("--early-exit", action="store_true", help="dubrovnik: the reference's loop (coverage quality, stop at 12 inliers)")
     ap.add_argument("--advanced", action="store_true",
                     help="dubrovnik: configs[3], the advanced processor (co-occurrence sampling over camera sets, 100 steps, no early exit)")
+    ap.add_argument("--host-queries", action="store_true", help="dubrovnik: every pass hands the queries over as host arrays (pose_amd_ransac_batch: "
+                                                                "packing and the PCIe copy inside the timed region) instead of running a list resident in HBM")
     ap.add_argument("--python-threads", action="store_true", help="dubrovnik: drive the contexts from Python threads instead of pose_amd_ransac_batch")
     ap.add_argument("--host-threads", type=int, default=16, help="dubrovnik: contexts (streams) per GPU driven concurrently")
     return ap.parse_args()
@@ -381,6 +383,8 @@ def bench_dubrovnik(args):
     # the descriptor array of the batch is built once: a pass is the library call alone, and its
     # result records are turned into (steps, inliers, camera error) after the timed region
     prep = ctxs[0].prepare_batch([q for _, q in queries]) if batched else None
+    # ... and uploaded once: the timed region starts with the queries resident in HBM
+    resident = ctxs[0].resident_batch(prep, with_camsets=args.advanced) if batched and not args.host_queries else None
 
     def convert(raw):
         from pose_estimation_amd.api import result_dict
@@ -392,6 +396,8 @@ def bench_dubrovnik(args):
 
     def one_pass(pool):
         res = []
+        if resident is not None:
+            return resident.run(sample_mode, seed=3000, budget=args.budget, select_mode=select, early_exit=args.early_exit, raw=True)
         if batched:
             return ctxs[0].ransac_batch(prep, sample_mode, seed=3000, budget=args.budget, select_mode=select,
                                         early_exit=args.early_exit, raw=True)
@@ -438,8 +444,12 @@ def bench_dubrovnik(args):
                                       "4000-6000 matches, 10-40%% inliers, %s"
                                       % (3 if args.advanced else 2, nq, sum(1 for i in range(nq) if shapes[i % len(shapes)][2] > 0),
                                          sum(1 for i in range(nq) if shapes[i % len(shapes)][2] == 0), mode),
-                          "parallelism": "queries partitioned over %d GPU(s), %s" % (world, "%d worker threads / streams per GPU inside pose_amd_ransac_batch" % T if batched
-                                                                                      else "%d host threads (contexts) per GPU" % T),
+                          "parallelism": "queries partitioned over %d GPU(s), %s" % (
+                              world, "%d host threads (contexts) per GPU" % T if not batched
+                              else "%d worker threads / streams per GPU inside the library (one launch sequence per query)" % T if select == SELECT_INLIERS
+                              else "all queries of a GPU share their launches (rounds of 64, 128, ... steps, list of running queries kept on the device)"),
+                          "queries": "resident in HBM (pose_amd_batch_create before the timed region, pose_amd_batch_run timed)" if resident is not None
+                                     else "host arrays handed over in every pass (packing + PCIe copy inside the timed region)",
                           "hypotheses_per_s": round(steps_total * args.steps / dt, 1),
                           "mean_steps_per_query": round(steps_total / max(len(res), 1), 1),
                           "queries_within_2_units_of_true_position": located}}
@@ -474,6 +484,8 @@ def bench_dubrovnik(args):
             if not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline_batch(ctxs[0], queries, args, select, sample_mode)
         print(json.dumps(out))
+    if resident is not None:
+        resident.close()
     for c in ctxs:
         c.close()
     if world > 1:

@@ -161,13 +161,32 @@ typedef struct {
 } pose_amd_query;
 
 /* Runs QueryProcessorBasic/Advanced::Process (from good_matches on) for `nq` independent
- * queries: per query pose_amd_set_query [+ set_camsets] + pose_amd_sample(sample_mode, seed,
- * query_id, 0, budget) + pose_amd_ransac_run(params), with identical results, but several
- * internal worker threads (each with its own stream; count from POSE_AMD_BATCH_LANES, default 8)
- * share the queries so that the small launches of different queries overlap on the device.
+ * queries -- the loop of benchmark.cpp:24-36 in one call: per query pose_amd_set_query
+ * [+ set_camsets] + pose_amd_sample(sample_mode, seed, query_id, 0, budget) +
+ * pose_amd_ransac_run(params), with bit-identical results.
+ * With the reference's selection (POSE_AMD_SELECT_COVERAGE) all queries share their launches:
+ * rounds of 64, 128, 256, ... RANSAC steps run for every query whose loop has not ended, the
+ * device keeps that list itself and the host waits once, at the end.  With inlier-count selection
+ * (or POSE_AMD_BATCH=threads in the environment) internal worker threads, each with its own
+ * stream (count from POSE_AMD_BATCH_LANES, default 8), run one launch sequence per query.
  * results[nq].  The context's own resident query is not touched. */
 int pose_amd_ransac_batch(pose_amd_ctx *ctx, int nq, const pose_amd_query *queries, int sample_mode, uint64_t seed,
                           uint32_t budget, const pose_amd_params *params, pose_amd_result *results);
+
+/* The same with the query list resident on the device -- what the reference holds in memory after
+ * LoadQueries / parse_bundler (benchmark.cpp:24: the loop runs over queries already loaded).
+ * pose_amd_batch_create validates the queries as pose_amd_ransac_batch does (camera sets only
+ * when with_camsets != 0; advanced sampling needs them), copies them (the caller's arrays are
+ * not referenced afterwards) and uploads them once; pose_amd_batch_run may then be called any
+ * number of times, with any mode, seed, budget and parameters, and returns what
+ * pose_amd_ransac_batch returns for the same list.  Calls on batches of one context must not
+ * overlap each other or other calls on that context; destroy the batches before the context. */
+typedef struct pose_amd_batch pose_amd_batch;
+int pose_amd_batch_create(pose_amd_ctx *ctx, int nq, const pose_amd_query *queries, int with_camsets, pose_amd_batch **out);
+int pose_amd_batch_size(const pose_amd_batch *batch);
+int pose_amd_batch_run(pose_amd_batch *batch, int sample_mode, uint64_t seed, uint32_t budget, const pose_amd_params *params,
+                       pose_amd_result *results);
+void pose_amd_batch_destroy(pose_amd_batch *batch);
 
 /* ---- several GPUs of one node from one host process (the loop of benchmark.cpp:24 over devices) -- */
 /* Assignment of queries to `nparts` parts by descending cost (match count), each to the least

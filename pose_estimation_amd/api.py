@@ -39,6 +39,36 @@ class PreparedBatch:
         self.nq, self.descs, self._keep = nq, descs, keep
 
 
+class ResidentBatch:
+    """A query list uploaded once (pose_amd_batch_create); run() may be called any number of times.
+    Close it (or let it be collected) before its context is closed."""
+    def __init__(self, ctx, queries, with_camsets=False):
+        prep = queries if isinstance(queries, PreparedBatch) else ctx.prepare_batch(queries)
+        self._ctx, self.nq = ctx, prep.nq
+        self._b = C.c_void_p()
+        ctx._chk(ctx._lib.pose_amd_batch_create(ctx._h, prep.nq, prep.descs, int(bool(with_camsets)), C.byref(self._b)), "batch_create")
+
+    def run(self, sample_mode=SAMPLE_BASIC, seed=0, budget=10000, select_mode=SELECT_COVERAGE, eps=0.5, early_exit=True, inlier_divisor=10,
+            inlier_absolute=12, raw=False):
+        """What Context.ransac_batch returns for the same list."""
+        prm = Params(int(select_mode), float(eps), int(bool(early_exit)), int(inlier_divisor), int(inlier_absolute))
+        res = (Result * max(self.nq, 1))()
+        self._ctx._chk(self._ctx._lib.pose_amd_batch_run(self._b, int(sample_mode), int(seed), int(budget), C.byref(prm), res), "batch_run")
+        return res if raw else [result_dict(r) for r in res[:self.nq]]
+
+    def close(self):
+        if self._b:
+            self._ctx._lib.pose_amd_batch_destroy(self._b)
+            self._b = C.c_void_p()
+
+    def __del__(self):
+        try:
+            if self._ctx._h:
+                self.close()
+        except Exception:
+            pass
+
+
 def result_dict(r):
     return dict(found=r.found, focal=r.focal, C=np.array(r.C[:]), Rc=np.array(r.Rc[:]).reshape(3, 3), inliers=r.inliers,
                 area_fit=r.area_fit, area_all=r.area_all, steps=r.steps, best_hyp=r.best_hyp, best_sol=r.best_sol,
@@ -230,6 +260,10 @@ class Context:
             d.width, d.height, d.focal = int(q["width"]), int(q["height"]), float(q["focal"])
             d.query_id = int(q.get("query_id", i))
         return PreparedBatch(nq, descs, keep)
+
+    def resident_batch(self, queries, with_camsets=False):
+        """Uploads a query list once; see ResidentBatch."""
+        return ResidentBatch(self, queries, with_camsets)
 
     def ransac_batch(self, queries, sample_mode=SAMPLE_BASIC, seed=0, budget=10000, select_mode=SELECT_COVERAGE, eps=0.5,
                      early_exit=True, inlier_divisor=10, inlier_absolute=12, raw=False):

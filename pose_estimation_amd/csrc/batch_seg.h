@@ -5,8 +5,15 @@
 // too few for 256 compute units, so their time is launch and dependency latency.  The kernels
 // here run the same device code for a whole group of queries at once: blockIdx.y (or .z) picks
 // the query from a descriptor table, and each query owns a segment of `S` steps in every
-// per-hypothesis array (hypothesis index = position in the group * S + step, pose slot = that
+// per-hypothesis array (hypothesis index = position in the pass * S + step, pose slot = that
 // * maxsol + solution).  Results are identical to the per-query launches.
+//
+// The host never waits between rounds.  Which queries still run is decided on the device:
+// k_seg_compact lists the queries of one solver whose loop has not ended, every other kernel
+// leaves at once when its position lies behind the end of that list, and the launch grids are
+// sized for the largest list possible.  A round whose list may be longer than the
+// per-hypothesis arrays have room for is issued as several passes over consecutive parts of
+// the list.
 #pragma once
 #include "kernels.h"
 
@@ -26,18 +33,48 @@ struct seg_query {
 // what a launch needs to find its query and its segment
 struct seg_launch {
     const seg_query *qt;
-    const int *active;           // query indices of the group, one per blockIdx.y / .z
+    const int *active;           // query indices that still run, built by k_seg_compact
+    const int *n_active;         // length of that list
+    int a0;                      // first list position of this pass; blockIdx.y / .z counts from it
     int S;                       // segment length: steps a query has room for in every per-hypothesis array
     int V;                       // steps of the round (<= S)
     uint32_t step0;              // first step of the round
 };
 
-__device__ __forceinline__ const seg_query &seg_of(const seg_launch &L, int a) { return L.qt[L.active[a]]; }
+// position p of the pass (block-uniform): false when the list ends before it
+__device__ __forceinline__ bool seg_live(const seg_launch &L, int p) { return L.a0 + p < *L.n_active; }
+__device__ __forceinline__ int seg_index(const seg_launch &L, int p) { return L.active[L.a0 + p]; }
+__device__ __forceinline__ const seg_query &seg_of(const seg_launch &L, int p) { return L.qt[seg_index(L, p)]; }
+
+// The queries among cand[0 .. ncand) whose loop goes on: not ended (state word 5), not handed to
+// the per-query path (word 7), and -- with early exit -- no kept pose with >= thresh inliers.
+// One block; the list keeps the order of cand.
+__global__ __launch_bounds__(COVSEL_THREADS) void k_seg_compact(const seg_query *__restrict__ qt, const int *__restrict__ cand, int ncand,
+                                                                 const unsigned long long *__restrict__ state, int early_exit,
+                                                                 int *__restrict__ active, int *__restrict__ n_active)
+{
+    __shared__ int s_tmp[COVSEL_THREADS / 64];
+    int n = 0;
+    for (int base = 0; base < ncand; base += COVSEL_THREADS) {
+        const int i = base + threadIdx.x;
+        int on = 0, qi = 0;
+        if (i < ncand) {
+            qi = cand[i];
+            const unsigned long long *w = state + (size_t)qi * 33;
+            on = !(w[5] != 0ull || w[7] != 0ull || (early_exit && w[2] != 0ull && w[1] >= (unsigned long long)qt[qi].thresh));
+        }
+        int total;
+        const int off = n + covsel_block_scan(on, 0, covsel_add(), s_tmp, total);
+        if (on) active[off] = qi;
+        n += total;
+    }
+    if (threadIdx.x == 0) *n_active = n;
+}
 
 __global__ void k_seg_sample_basic(seg_launch L, uint64_t seed, uint32_t *__restrict__ samples)
 {
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= (uint32_t)L.V) return;
+    if (j >= (uint32_t)L.V || !seg_live(L, blockIdx.y)) return;
     const seg_query &sq = seg_of(L, blockIdx.y);
     sample_basic_one(sq.q, sq.maxsol == P4PF_MAXSOL ? 4 : 3, seed, sq.query_id, L.step0 + j, samples, (size_t)blockIdx.y * L.S + j);
 }
@@ -50,7 +87,7 @@ __global__ __launch_bounds__(64 * SAMPLE_ADV_WAVES) void k_seg_sample_advanced(s
     extern __shared__ uint32_t s_cam_bits[];
     const int wave = threadIdx.x >> 6;
     const uint32_t j = blockIdx.x * SAMPLE_ADV_WAVES + wave;
-    if (j >= (uint32_t)L.V) return;                      // whole waves leave together
+    if (j >= (uint32_t)L.V || !seg_live(L, blockIdx.y)) return;   // whole waves leave together
     const seg_query &sq = seg_of(L, blockIdx.y);
     const int m = sq.maxsol == P4PF_MAXSOL ? 4 : 3;
     const size_t t = (size_t)blockIdx.y * L.S + j;
@@ -64,7 +101,7 @@ __global__ __launch_bounds__(64) void k_seg_solve_p3p(seg_launch L, const uint32
                                                       int *__restrict__ nsol, float *__restrict__ projf, double eps)
 {
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= (uint32_t)L.V) return;
+    if (j >= (uint32_t)L.V || !seg_live(L, blockIdx.y)) return;
     solve_p3p_one(seg_of(L, blockIdx.y).q, (size_t)blockIdx.y * L.S + j, samples, proj, pose, nsol, projf, eps);
 }
 
@@ -72,6 +109,7 @@ __global__ __launch_bounds__(64) void k_seg_solve_p3p(seg_launch L, const uint32
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_seg_p4pf_elim(seg_launch L, const uint32_t *__restrict__ samples,
                                                                                                  double *__restrict__ Arows, int *__restrict__ status, int batch)
 {
+    if (!seg_live(L, blockIdx.y)) return;
     const size_t base = (size_t)blockIdx.y * L.S;
     p4pf_elim_block(seg_of(L, blockIdx.y).q, (uint32_t)L.V, samples + base * 4, nullptr, nullptr, Arows + base, (size_t)gridDim.y * L.S, status + base, batch,
                     blockIdx.x, gridDim.x);
@@ -82,6 +120,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                                                                                                    double *__restrict__ proj, double *__restrict__ pose,
                                                                                                    int *__restrict__ nsol, float *__restrict__ projf, double eps)
 {
+    if (!seg_live(L, blockIdx.y)) return;
     const size_t base = (size_t)blockIdx.y * L.S, sbase = base * P4PF_MAXSOL;
     p4pf_finish_block(seg_of(L, blockIdx.y).q, (uint32_t)L.V, samples + base * 4, nullptr, nullptr, Arows + base, (size_t)gridDim.y * L.S, status + base,
                       proj + sbase * 12, pose + sbase * 13, nsol + base, nullptr, nullptr, nullptr, projf + sbase * 32, eps, blockIdx.x);
@@ -96,6 +135,7 @@ __global__ __launch_bounds__(SCORE_THREADS) __attribute__((amdgpu_waves_per_eu(6
     __shared__ int s_cnt[SCORE_SPB];
     __shared__ int s_list[SCORE_SPB];
     __shared__ int s_wave_n[SCORE_THREADS / 64];
+    if (!seg_live(L, blockIdx.y)) return;
     const size_t base = (size_t)blockIdx.y * L.S, sbase = base * maxsol;
     score_screen_block<false>(seg_of(L, blockIdx.y).q, L.V * maxsol, proj + sbase * 12, projf + sbase * 32, nsol + base, maxsol, eps, counts + sbase,
                               nullptr, 0, spb, blockIdx.x, s_cnt, s_list, s_wave_n);
@@ -119,9 +159,10 @@ __global__ __launch_bounds__(COVSEL_THREADS) void k_seg_cov_records(seg_launch L
 {
     __shared__ int s_tmp[COVSEL_THREADS / 64];
     const int a = blockIdx.x;
+    if (!seg_live(L, a)) return;
     const seg_query &sq = seg_of(L, a);
     const size_t base = (size_t)a * L.S;
-    cov_records_block(L.V * sq.maxsol, counts + base * sq.maxsol, nsol + base, sq.maxsol, sq.box, C.state + (size_t)L.active[a] * 33,
+    cov_records_block(L.V * sq.maxsol, counts + base * sq.maxsol, nsol + base, sq.maxsol, sq.box, C.state + (size_t)seg_index(L, a) * 33,
                       C.list1 + (size_t)a * C.cap1, C.n + 4 * a, C.cap1, s_tmp);
 }
 
@@ -133,6 +174,7 @@ __global__ __launch_bounds__(256) void k_seg_coverage(seg_launch L, seg_cov C, i
     __shared__ unsigned long long s_sum[256];
     __shared__ int s_any;
     const int a = blockIdx.z;
+    if (!seg_live(L, a)) return;
     const seg_query &sq = seg_of(L, a);
     if ((int)blockIdx.y >= sq.bands) return;
     const int cap = which ? C.cap2 : C.cap1;
@@ -154,6 +196,7 @@ __global__ __launch_bounds__(256) void k_seg_coverage_all(seg_launch L, unsigned
     __shared__ unsigned long long s_sum[256];
     __shared__ int s_any;
     const int a = blockIdx.z;
+    if (!seg_live(L, a)) return;
     const seg_query &sq = seg_of(L, a);
     unsigned long long *out = sums + (size_t)a * bands_max;
     if ((int)blockIdx.y >= sq.bands) { if (threadIdx.x == 0) out[blockIdx.y] = 0ull; return; }
@@ -168,13 +211,14 @@ __global__ __launch_bounds__(COVSEL_THREADS) void k_seg_cov_candidates(seg_launc
     __shared__ int s_tmp[COVSEL_THREADS / 64];
     __shared__ int s_limit;
     const int a = blockIdx.x;
+    if (!seg_live(L, a)) return;
     const seg_query &sq = seg_of(L, a);
     const size_t base = (size_t)a * L.S;
     if (C.n[4 * a] > C.cap1) {                           // truncated record list (block-uniform): k_seg_cov_final reports it
         if (threadIdx.x == 0) C.n[4 * a + 1] = 0;
         return;
     }
-    cov_candidates_block(L.V * sq.maxsol, counts + base * sq.maxsol, nsol + base, sq.maxsol, sq.box, C.state + (size_t)L.active[a] * 33,
+    cov_candidates_block(L.V * sq.maxsol, counts + base * sq.maxsol, nsol + base, sq.maxsol, sq.box, C.state + (size_t)seg_index(L, a) * 33,
                          C.list1 + (size_t)a * C.cap1, C.n + 4 * a, C.bands1 + (size_t)a * C.cap1 * C.bands_max, sq.bands,
                          C.area1 + (size_t)a * 2 * C.cap1, C.list2 + (size_t)a * C.cap2, C.cap2, sq.thresh, early_exit, s_tmp, s_limit);
 }
@@ -182,15 +226,18 @@ __global__ __launch_bounds__(COVSEL_THREADS) void k_seg_cov_candidates(seg_launc
 // state word 7 is set to 1 when the query had more candidates than the launch has room for (or the
 // shortened replay did not end the loop): the caller then runs that query through the per-query
 // path instead.
+// totals[query][4] accumulate over the rounds: steps, poses scored, ((step of the kept pose + 1) << 8
+// | its solution) or 0, unused.  The state words of a query keep the kept pose's record and matrix.
 __global__ __launch_bounds__(COVSEL_THREADS) void k_seg_cov_final(seg_launch L, seg_cov C, int early_exit, const int *__restrict__ counts,
                                                                    const int *__restrict__ nsol, const double *__restrict__ pose,
-                                                                   const double *__restrict__ proj)
+                                                                   const double *__restrict__ proj, unsigned long long *__restrict__ totals)
 {
     __shared__ cov_final_lds lds;
     const int a = blockIdx.x;
+    if (!seg_live(L, a)) return;
     const seg_query &sq = seg_of(L, a);
     const size_t base = (size_t)a * L.S, sbase = base * sq.maxsol;
-    unsigned long long *state = C.state + (size_t)L.active[a] * 33;
+    unsigned long long *state = C.state + (size_t)seg_index(L, a) * 33;
     if (C.n[4 * a] > C.cap1 || C.n[4 * a + 1] > C.cap2) {   // block-uniform
         if (threadIdx.x == 0) state[7] = 1ull;
         return;
@@ -199,6 +246,12 @@ __global__ __launch_bounds__(COVSEL_THREADS) void k_seg_cov_final(seg_launch L, 
                     C.n + 4 * a, C.area1 + (size_t)a * 2 * C.cap1, C.list2 + (size_t)a * C.cap2,
                     C.bands2 + (size_t)a * C.cap2 * C.bands_max, sq.bands, C.mslot + (size_t)a * (C.cap1 + C.cap2), C.marea + (size_t)a * (C.cap1 + C.cap2),
                     C.mkeep + (size_t)a * (C.cap1 + C.cap2), pose + sbase * 13, proj + sbase * 12, state, lds);
+    // thread 0 wrote words 3..7 itself
+    if (threadIdx.x == 0 && state[7] == 0ull) {
+        unsigned long long *t = totals + (size_t)seg_index(L, a) * 4;
+        t[0] += state[3]; t[1] += state[4];
+        if (state[6] != ~0ull) t[2] = (((unsigned long long)L.step0 + state[6] / (unsigned)sq.maxsol + 1ull) << 8) | (state[6] % (unsigned)sq.maxsol);
+    }
 }
 
 } // namespace pose_amd

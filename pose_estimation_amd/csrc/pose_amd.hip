@@ -8,6 +8,7 @@
 #include <atomic>
 #include <mutex>
 #include <thread>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -88,10 +89,11 @@ struct pose_amd_ctx {
                                    // every event is one more command for the GPU's command processor)
     // batch entry point: child contexts (one stream each)
     std::vector<pose_amd_ctx *> lanes;
+    struct pose_amd_batch *own_batch = nullptr;   // resident list behind pose_amd_ransac_batch
     // segmented batch (many queries per launch): packed queries, descriptor table, per-hypothesis arrays, selection scratch
-    dev_buf sg_qpack, sg_qtab, sg_active, sg_samples, sg_sstatus, sg_arows, sg_pstatus, sg_proj, sg_pose, sg_projf, sg_nsol, sg_counts, sg_state, sg_n,
+    dev_buf sg_samples, sg_sstatus, sg_arows, sg_pstatus, sg_proj, sg_pose, sg_projf, sg_nsol, sg_counts, sg_n,
         sg_list1, sg_area1, sg_bands1, sg_list2, sg_bands2, sg_mslot, sg_marea, sg_mkeep, sg_allsums;
-    pin_buf sgh_qpack, sgh_qtab, sgh_active, sgh_state, sgh_allsums;
+    pin_buf sgh_allsums;
     // hypotheses
     uint32_t hyp_count = 0;
     int solver = POSE_AMD_SOLVER_P4PF;
@@ -166,6 +168,8 @@ static query_dev make_query(const pose_amd_ctx *c)
     q.xmax = c->xmax; q.umax = c->umax;
     return q;
 }
+
+static void batch_free(struct pose_amd_batch *b);
 
 static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 
@@ -269,16 +273,17 @@ void pose_amd_destroy(pose_amd_ctx *c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    batch_free(c->own_batch);
     dev_buf *bufs[] = {&c->qpack, &c->cam_off, &c->cam_ids, &c->gain, &c->samples,
                        &c->sample_status, &c->proj, &c->pose, &c->nsol, &c->counts, &c->sel, &c->bitmaps, &c->areas,
                        &c->maskw, &c->arows, &c->pstatus, &c->projf, &c->feat, &c->vlist, &c->vcount, &c->arows2, &c->pstatus2, &c->vlist2, &c->vcount2, &c->in0, &c->in1, &c->in2, &c->out0, &c->out1, &c->out2, &c->out3,
                        &c->cov_state, &c->cov_n, &c->cov_list1, &c->cov_bands1, &c->cov_area1, &c->cov_list2, &c->cov_bands2, &c->cov_mslot, &c->cov_marea,
-                       &c->cov_mkeep, &c->sg_qpack, &c->sg_qtab, &c->sg_active, &c->sg_samples, &c->sg_sstatus, &c->sg_arows, &c->sg_pstatus, &c->sg_proj,
-                       &c->sg_pose, &c->sg_projf, &c->sg_nsol, &c->sg_counts, &c->sg_state, &c->sg_n, &c->sg_list1, &c->sg_area1, &c->sg_bands1, &c->sg_list2,
+                       &c->cov_mkeep, &c->sg_samples, &c->sg_sstatus, &c->sg_arows, &c->sg_pstatus, &c->sg_proj,
+                       &c->sg_pose, &c->sg_projf, &c->sg_nsol, &c->sg_counts, &c->sg_n, &c->sg_list1, &c->sg_area1, &c->sg_bands1, &c->sg_list2,
                        &c->sg_bands2, &c->sg_mslot, &c->sg_marea, &c->sg_mkeep, &c->sg_allsums};
     for (dev_buf *b : bufs) if (b->p) (void)hipFree(b->p);
     if (c->qstage) (void)hipHostFree(c->qstage);
-    pin_buf *pins[] = {&c->band_host, &c->h_words, &c->sgh_qpack, &c->sgh_qtab, &c->sgh_active, &c->sgh_state, &c->sgh_allsums};
+    pin_buf *pins[] = {&c->band_host, &c->h_words, &c->sgh_allsums};
     for (pin_buf *b : pins) if (b->p) (void)hipHostFree(b->p);
     for (int i = 0; i < 6; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
     for (int i = 0; i < 6; ++i) if (c->ev2[i]) (void)hipEventDestroy(c->ev2[i]);
@@ -1126,28 +1131,49 @@ static bool coverage_geometry(int width, int height, int &band_rows, int &bands,
     return true;
 }
 
-// QueryProcessorBasic/Advanced::Process for many queries with the reference's selection (coverage
-// quality), many queries per launch: all queries are packed and uploaded once; rounds of
-// 1 024, 4 096, ... steps run over the queries that have not finished (all of them in one launch
-// sequence per solver), one download of the per-query selection state ends a round.  Results equal
-// the per-query sequence set_query + sample + ransac_run.  fallback[i] is set for queries that must
-// take the per-query path instead (more candidates than a launch has room for).
-static int ransac_batch_segmented(pose_amd_ctx *ctx, int nq, const pose_amd_query *queries, int sample_mode, uint64_t seed, uint32_t budget,
-                                  const pose_amd_params *prm, pose_amd_result *results, std::vector<char> &fallback)
+// A list of queries resident on the device: the packed correspondence arrays, the descriptor table
+// of the segmented kernels and what depends on the queries alone (coverage geometry, all-matches
+// areas).  A host copy of the arrays stays for the queries that take the per-query path.
+struct pose_amd_batch {
+    pose_amd_ctx *ctx = nullptr;
+    int nq = 0;
+    bool has_cams = false;                    // every query came with camera sets (checked as set_camsets checks them)
+    std::vector<pose_amd_query> host_q;       // the queries again, pointing into hpack
+    pin_buf hpack;                            // page-locked: the upload reads it directly
+    std::vector<seg_query> qt;                // host copy of the table (thresh is filled in per run)
+    std::vector<int64_t> area_all;
+    dev_buf qpack, qtab, lists, state, totals;
+    pin_buf h_qtab, h_lists, h_out;
+    int bands_max = 1, bm_max = 0;
+    size_t lds_cov = 0;
+};
+
+static void batch_free(pose_amd_batch *b)
 {
-    const bool advanced = sample_mode == POSE_AMD_SAMPLE_ADVANCED;
-    const bool early = prm->early_exit != 0;
-    fallback.assign((size_t)nq, 0);
-    int rc;
-    // ---- layout of the packed correspondence arrays and validation ------------------------------
-    struct qinfo { size_t off; size_t b; size_t cam_off_at, cam_ids_at; bool live; int maxsol; };
-    std::vector<qinfo> qi((size_t)nq);
+    if (!b) return;
+    dev_buf *bufs[] = {&b->qpack, &b->qtab, &b->lists, &b->state, &b->totals};
+    for (dev_buf *d : bufs) if (d->p) { (void)hipFree(d->p); d->p = nullptr; d->cap = 0; }
+    pin_buf *pins[] = {&b->hpack, &b->h_qtab, &b->h_lists, &b->h_out};
+    for (pin_buf *d : pins) if (d->p) { (void)hipHostFree(d->p); d->p = nullptr; d->cap = 0; }
+    delete b;
+}
+
+// Validation (the checks of set_query, sample and set_camsets, per query), packing, upload, areas.
+// `b` may be a batch built earlier on the same context: its buffers are reused.
+static int batch_fill(pose_amd_ctx *ctx, pose_amd_batch *b, int nq, const pose_amd_query *queries, bool with_cams, const char *who)
+{
+    b->ctx = ctx;
+    b->nq = 0;                                 // until everything below has succeeded
+    const std::string pre = std::string(who) + ": query ";
+    struct place { size_t off, stride, cam_off_at, cam_ids_at; };
+    std::vector<place> at((size_t)nq);
     size_t total = 0;
+    const bool all_cams = with_cams;
+    b->has_cams = with_cams;
     for (int i = 0; i < nq; ++i) {
         const pose_amd_query &q = queries[i];
-        memset(&results[i], 0, sizeof results[i]);
         if (q.n < 0 || q.width <= 0 || q.height <= 0 || (q.n && (!q.kx || !q.ky || !q.X || !q.Y || !q.Z)) || !(q.focal >= 0.0))
-            return fail(ctx, POSE_AMD_EINVAL, ("ransac_batch: query " + std::to_string(i) + ": set_query: bad argument").c_str());
+            return fail(ctx, POSE_AMD_EINVAL, (pre + std::to_string(i) + ": set_query: bad argument").c_str());
         const int m = q.focal == 0.0 ? 4 : 3;
         int distinct = std::min(q.n, 4);
         if (q.lindex) {
@@ -1159,45 +1185,44 @@ static int ransac_batch_segmented(pose_amd_ctx *ctx, int nq, const pose_amd_quer
                 if (!dup) seen[distinct++] = q.lindex[k];
             }
         }
-        if (q.n <= 0) return fail(ctx, POSE_AMD_ESTATE, ("ransac_batch: query " + std::to_string(i) + ": sample: no query set").c_str());
+        if (q.n <= 0) return fail(ctx, POSE_AMD_ESTATE, (pre + std::to_string(i) + ": sample: no query set").c_str());
         if (q.n < m || distinct < m)
-            return fail(ctx, POSE_AMD_EINVAL, ("ransac_batch: query " + std::to_string(i) + ": sample: fewer correspondences (distinct keypoints) than the minimal sample size").c_str());
-        qinfo &e = qi[(size_t)i];
-        e.b = (((size_t)q.n * 4) + 255) / 256 * 256;
+            return fail(ctx, POSE_AMD_EINVAL, (pre + std::to_string(i) + ": sample: fewer correspondences (distinct keypoints) than the minimal sample size").c_str());
+        place &e = at[(size_t)i];
+        e.stride = (((size_t)q.n * 4) + 255) / 256 * 256;
         e.off = total;
-        e.maxsol = q.focal == 0.0 ? P4PF_MAXSOL : P3P_MAXSOL;
-        total += e.b * (q.lindex ? 6 : 5);
+        total += e.stride * (q.lindex ? 6 : 5);
         e.cam_off_at = e.cam_ids_at = 0;
-        if (advanced) {
-            if (!q.cam_off || !q.cam_ids || q.cam_off[0] != 0)
-                return fail(ctx, POSE_AMD_EINVAL, ("ransac_batch: query " + std::to_string(i) + ": set_camsets: no query or bad argument").c_str());
+        if (all_cams) {
+            if (!q.cam_off || !q.cam_ids || q.cam_off[0] != 0) return fail(ctx, POSE_AMD_EINVAL, (pre + std::to_string(i) + ": set_camsets: no query or bad argument").c_str());
             bool any5 = false;
             for (int k = 0; k < q.n; ++k) {
-                if (q.cam_off[k + 1] < q.cam_off[k]) return fail(ctx, POSE_AMD_EINVAL, "ransac_batch: set_camsets: offsets must be non-decreasing");
+                if (q.cam_off[k + 1] < q.cam_off[k]) return fail(ctx, POSE_AMD_EINVAL, (pre + std::to_string(i) + ": set_camsets: offsets must be non-decreasing").c_str());
                 const uint32_t sz = q.cam_off[k + 1] - q.cam_off[k];
-                if (sz > (uint32_t)MAXCAM) return fail(ctx, POSE_AMD_EINVAL, "ransac_batch: set_camsets: a camera set exceeds 128 entries");
+                if (sz > (uint32_t)MAXCAM) return fail(ctx, POSE_AMD_EINVAL, (pre + std::to_string(i) + ": set_camsets: a camera set exceeds 128 entries").c_str());
                 any5 |= sz >= 5;
                 for (uint32_t c = q.cam_off[k] + 1; c < q.cam_off[k + 1]; ++c)
-                    if (q.cam_ids[c] <= q.cam_ids[c - 1]) return fail(ctx, POSE_AMD_EINVAL, "ransac_batch: set_camsets: ids must be strictly increasing per set");
+                    if (q.cam_ids[c] <= q.cam_ids[c - 1])
+                        return fail(ctx, POSE_AMD_EINVAL, (pre + std::to_string(i) + ": set_camsets: ids must be strictly increasing per set").c_str());
             }
-            if (!any5) return fail(ctx, POSE_AMD_EINVAL, ("ransac_batch: query " + std::to_string(i) + ": set_camsets: no correspondence has >= 5 cameras").c_str());
+            if (!any5) return fail(ctx, POSE_AMD_EINVAL, (pre + std::to_string(i) + ": set_camsets: no correspondence has >= 5 cameras").c_str());
             e.cam_off_at = total;
             total += (((size_t)q.n + 1) * 4 + 255) / 256 * 256;
             e.cam_ids_at = total;
             total += ((size_t)std::max<uint32_t>(q.cam_off[q.n], 1u) * 4 + 255) / 256 * 256;
         }
-        const unsigned thresh = std::min((unsigned)q.n / prm->inlier_divisor, (unsigned)prm->inlier_absolute);
-        e.live = budget > 0 && !(early && thresh == 0);             // otherwise the reference's loop body never runs
     }
-    if ((rc = ensure(ctx, ctx->sg_qpack, total)) || (rc = ensure_pinned(ctx, ctx->sgh_qpack, total)) ||
-        (rc = ensure(ctx, ctx->sg_qtab, (size_t)nq * sizeof(seg_query))) || (rc = ensure_pinned(ctx, ctx->sgh_qtab, (size_t)nq * sizeof(seg_query))) ||
-        (rc = ensure(ctx, ctx->sg_state, (size_t)nq * 33 * 8)) || (rc = ensure_pinned(ctx, ctx->sgh_state, (size_t)nq * 33 * 8)))
+    int rc;
+    if ((rc = ensure(ctx, b->qpack, total)) || (rc = ensure_pinned(ctx, b->hpack, total)) || (rc = ensure(ctx, b->qtab, (size_t)nq * sizeof(seg_query))) ||
+        (rc = ensure_pinned(ctx, b->h_qtab, (size_t)nq * sizeof(seg_query))) || (rc = ensure(ctx, b->lists, (size_t)nq * 16 + 64)) ||
+        (rc = ensure_pinned(ctx, b->h_lists, (size_t)nq * 8)) || (rc = ensure(ctx, b->state, (size_t)nq * 33 * 8)) ||
+        (rc = ensure(ctx, b->totals, (size_t)nq * 32)) || (rc = ensure_pinned(ctx, b->h_out, (size_t)nq * (33 + 4) * 8)))
         return rc;
+    b->qt.assign((size_t)nq, seg_query());
+    b->host_q.assign(queries, queries + nq);
+    b->area_all.assign((size_t)nq, 0);
     // ---- pack (a few host threads: the copies and the scans for the screens' bounds) -------------
-    seg_query *qt = (seg_query *)ctx->sgh_qtab.p;
-    char *hp = (char *)ctx->sgh_qpack.p, *dp = (char *)ctx->sg_qpack.p;
-    size_t lds_cov = 0;
-    int bands_max = 1, bm_max = 0;
+    char *hp = (char *)b->hpack.p, *dp = (char *)b->qpack.p;
     std::atomic<int> bad_geometry(0);
     {
         std::atomic<int> next(0);
@@ -1206,15 +1231,20 @@ static int ransac_batch_segmented(pose_amd_ctx *ctx, int nq, const pose_amd_quer
                 const int i = next.fetch_add(1);
                 if (i >= nq) return;
                 const pose_amd_query &q = queries[i];
-                const qinfo &e = qi[(size_t)i];
+                const place &e = at[(size_t)i];
+                pose_amd_query &hq = b->host_q[(size_t)i];
                 const void *src[6] = {q.kx, q.ky, q.X, q.Y, q.Z, q.lindex};
-                for (int a = 0; a < (q.lindex ? 6 : 5); ++a) memcpy(hp + e.off + e.b * a, src[a], (size_t)q.n * 4);
-                seg_query &sq = qt[i];
+                for (int a = 0; a < (q.lindex ? 6 : 5); ++a) memcpy(hp + e.off + e.stride * a, src[a], (size_t)q.n * 4);
+                hq.kx = (const float *)(hp + e.off); hq.ky = (const float *)(hp + e.off + e.stride); hq.X = (const float *)(hp + e.off + 2 * e.stride);
+                hq.Y = (const float *)(hp + e.off + 3 * e.stride); hq.Z = (const float *)(hp + e.off + 4 * e.stride);
+                hq.lindex = q.lindex ? (const uint32_t *)(hp + e.off + 5 * e.stride) : nullptr;
+                hq.cam_off = hq.cam_ids = nullptr;
+                seg_query &sq = b->qt[(size_t)i];
                 memset(&sq, 0, sizeof sq);
                 sq.q.n = q.n; sq.q.width = q.width; sq.q.height = q.height; sq.q.focal = q.focal;
-                sq.q.kx = (const float *)(dp + e.off); sq.q.ky = (const float *)(dp + e.off + e.b); sq.q.X = (const float *)(dp + e.off + 2 * e.b);
-                sq.q.Y = (const float *)(dp + e.off + 3 * e.b); sq.q.Z = (const float *)(dp + e.off + 4 * e.b);
-                sq.q.lindex = q.lindex ? (const uint32_t *)(dp + e.off + 5 * e.b) : nullptr;
+                sq.q.kx = (const float *)(dp + e.off); sq.q.ky = (const float *)(dp + e.off + e.stride); sq.q.X = (const float *)(dp + e.off + 2 * e.stride);
+                sq.q.Y = (const float *)(dp + e.off + 3 * e.stride); sq.q.Z = (const float *)(dp + e.off + 4 * e.stride);
+                sq.q.lindex = q.lindex ? (const uint32_t *)(dp + e.off + 5 * e.stride) : nullptr;
                 float xm = 0.f, um = 0.f;
                 bool finite = true;
                 for (int k = 0; k < q.n; ++k) {
@@ -1225,15 +1255,15 @@ static int ransac_batch_segmented(pose_amd_ctx *ctx, int nq, const pose_amd_quer
                 }
                 sq.q.xmax = finite ? xm : NAN; sq.q.umax = finite ? um * 1.000001f : NAN;
                 sq.query_id = q.query_id;
-                sq.maxsol = e.maxsol;
-                sq.thresh = std::min((unsigned)q.n / prm->inlier_divisor, (unsigned)prm->inlier_absolute);
+                sq.maxsol = q.focal == 0.0 ? P4PF_MAXSOL : P3P_MAXSOL;
                 const long long cover = (long long)std::ceil((float)q.width / 20.0f);
                 sq.box = (long long)(2 * (cover / 2)) * (2 * (cover / 2));
                 size_t lds = 0;
                 if (!coverage_geometry(q.width, q.height, sq.band_rows, sq.bands, sq.wpr, sq.separable, lds)) { bad_geometry = 1; continue; }
-                if (advanced) {
+                if (all_cams) {
                     memcpy(hp + e.cam_off_at, q.cam_off, ((size_t)q.n + 1) * 4);
                     memcpy(hp + e.cam_ids_at, q.cam_ids, (size_t)q.cam_off[q.n] * 4);
+                    hq.cam_off = (const uint32_t *)(hp + e.cam_off_at); hq.cam_ids = (const uint32_t *)(hp + e.cam_ids_at);
                     sq.q.cam_off = (const uint32_t *)(dp + e.cam_off_at); sq.q.cam_ids = (const uint32_t *)(dp + e.cam_ids_at);
                     uint32_t cam_max = 0;
                     for (int k = 0; k < q.n; ++k) if (q.cam_off[k + 1] > q.cam_off[k]) cam_max = std::max(cam_max, q.cam_ids[q.cam_off[k + 1] - 1]);
@@ -1248,19 +1278,91 @@ static int ransac_batch_segmented(pose_amd_ctx *ctx, int nq, const pose_amd_quer
         for (std::thread &t : pool) t.join();
     }
     if (bad_geometry.load()) return fail(ctx, POSE_AMD_EINVAL, "coverage: image wider than 393216 px");
+    b->lds_cov = 0; b->bands_max = 1; b->bm_max = 0;
     for (int i = 0; i < nq; ++i) {
         size_t lds = 0;
         int br, bn, wp, sep;
         coverage_geometry(queries[i].width, queries[i].height, br, bn, wp, sep, lds);
-        lds_cov = std::max(lds_cov, lds);
-        bands_max = std::max(bands_max, qt[i].bands);
-        bm_max = std::max(bm_max, qt[i].bm_words);
+        b->lds_cov = std::max(b->lds_cov, lds);
+        b->bands_max = std::max(b->bands_max, b->qt[(size_t)i].bands);
+        b->bm_max = std::max(b->bm_max, b->qt[(size_t)i].bm_words);
     }
-    HIPCHK(ctx, hipMemcpyAsync(ctx->sg_qpack.p, ctx->sgh_qpack.p, total, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(ctx, hipMemcpyAsync(ctx->sg_qtab.p, ctx->sgh_qtab.p, (size_t)nq * sizeof(seg_query), hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(ctx, hipMemsetAsync(ctx->sg_state.p, 0, (size_t)nq * 33 * 8, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(b->qpack.p, b->hpack.p, total, hipMemcpyHostToDevice, ctx->stream));
+    memcpy(b->h_qtab.p, b->qt.data(), (size_t)nq * sizeof(seg_query));
+    HIPCHK(ctx, hipMemcpyAsync(b->qtab.p, b->h_qtab.p, (size_t)nq * sizeof(seg_query), hipMemcpyHostToDevice, ctx->stream));
+    // all-matches areas (query_processor.cpp:154-169): every query is "active", the list is the identity
+    int *hl = (int *)b->h_lists.p;
+    for (int i = 0; i < nq; ++i) hl[i] = i;
+    hl[nq] = nq;
+    int *dl = (int *)b->lists.p;                                   // [0, nq): identity, [nq]: nq
+    HIPCHK(ctx, hipMemcpyAsync(dl, hl, ((size_t)nq + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
+    const size_t nb = (size_t)nq * b->bands_max * 8;
+    if ((rc = ensure(ctx, ctx->sg_allsums, nb)) || (rc = ensure_pinned(ctx, ctx->sgh_allsums, nb))) return rc;
+    for (int g0 = 0; g0 < nq; g0 += 32768) {
+        const int ng = std::min(32768, nq - g0);
+        seg_launch L{(const seg_query *)b->qtab.p, dl, dl + nq, g0, 0, 0, 0};
+        hipLaunchKernelGGL(k_seg_coverage_all, dim3(1, b->bands_max, (unsigned)ng), dim3(256), b->lds_cov, ctx->stream, L,
+                           (unsigned long long *)ctx->sg_allsums.p + (size_t)g0 * b->bands_max, b->bands_max);
+    }
+    HIPCHK(ctx, hipGetLastError());
+    if ((rc = download(ctx, ctx->sgh_allsums.p, ctx->sg_allsums.p, nb)) || (rc = pose_amd_synchronize(ctx))) return rc;
+    const unsigned long long *sums = (const unsigned long long *)ctx->sgh_allsums.p;
+    for (int i = 0; i < nq; ++i)
+        for (int k = 0; k < b->qt[(size_t)i].bands; ++k) b->area_all[(size_t)i] += (int64_t)sums[(size_t)i * b->bands_max + k];
+    b->nq = nq;
+    return POSE_AMD_OK;
+}
 
-    // ---- group helpers ------------------------------------------------------------------------------
+// QueryProcessorBasic/Advanced::Process for the queries of a resident list with the reference's
+// selection (coverage quality), many queries per launch.  Rounds of 64, 128, 256, ... steps; the
+// device keeps the list of queries whose loop has not ended (k_seg_compact) and the host issues
+// every round without waiting: one download of the per-query outcome ends the call.  Results equal
+// the per-query sequence set_query + sample + ransac_run.  fallback[i] is set for queries that must
+// take the per-query path instead (more candidates than a launch has room for).
+static int batch_run_segmented(pose_amd_batch *b, int sample_mode, uint64_t seed, uint32_t budget, const pose_amd_params *prm, pose_amd_result *results,
+                               std::vector<char> &fallback)
+{
+    pose_amd_ctx *ctx = b->ctx;
+    const int nq = b->nq;
+    const bool advanced = sample_mode == POSE_AMD_SAMPLE_ADVANCED;
+    const bool early = prm->early_exit != 0;
+    const bool stats = getenv("POSE_AMD_SEG_STATS") != nullptr;          // development aid: phase times on stderr
+    const auto t_begin = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (stats) fprintf(stderr, "seg: %-10s at %.3f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count());
+    };
+    fallback.assign((size_t)nq, 0);
+    int rc;
+    // ---- per run: thresholds, the queries of each solver whose loop body runs at all ----------------
+    seg_query *qt = (seg_query *)b->h_qtab.p;                         // staging copy of b->qt with this run's thresholds
+    memcpy(qt, b->qt.data(), (size_t)nq * sizeof(seg_query));
+    int *hl = (int *)b->h_lists.p;
+    int nsolver[2] = {0, 0};
+    std::vector<char> live((size_t)nq, 0);
+    for (int solver = 0; solver < 2; ++solver) {
+        int *dst = hl + (solver ? nsolver[0] : 0);
+        for (int i = 0; i < nq; ++i) {
+            seg_query &sq = qt[i];
+            if ((sq.maxsol == P4PF_MAXSOL) != (solver == 1)) continue;
+            sq.thresh = std::min((unsigned)sq.q.n / prm->inlier_divisor, (unsigned)prm->inlier_absolute);
+            memset(&results[i], 0, sizeof results[i]);
+            if (budget == 0 || (early && sq.thresh == 0)) continue;        // the reference's loop body never runs
+            live[(size_t)i] = 1;
+            dst[nsolver[solver]++] = i;
+        }
+    }
+    const int nlive = nsolver[0] + nsolver[1];
+    if (nlive == 0) return POSE_AMD_OK;
+    // lists: [0, nlive) the candidates of the two solvers, then per solver the active list and its length
+    int *dl = (int *)b->lists.p;
+    int *cand_dev[2] = {dl, dl + nsolver[0]};
+    int *active_dev[2] = {dl + nq, dl + nq + nsolver[0]};
+    int *nact_dev[2] = {dl + 2 * nq + 8, dl + 2 * nq + 9};
+    HIPCHK(ctx, hipMemcpyAsync(b->qtab.p, qt, (size_t)nq * sizeof(seg_query), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(dl, hl, (size_t)nlive * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(b->state.p, 0, (size_t)nq * 33 * 8, ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(b->totals.p, 0, (size_t)nq * 32, ctx->stream));
+
     // room per query and round for count records / candidates of the selection; a query that needs more
     // takes the per-query path (POSE_AMD_SEG_CAPS="records,candidates" shrinks them, for tests of that route)
     int cap1 = 512, cap2 = 4096;
@@ -1268,40 +1370,6 @@ static int ransac_batch_segmented(pose_amd_ctx *ctx, int nq, const pose_amd_quer
         int a1 = 0, a2 = 0;
         if (sscanf(e, "%d,%d", &a1, &a2) == 2 && a1 > 0 && a2 > 0) { cap1 = std::min(a1, cap1); cap2 = std::min(a2, cap2); }
     }
-    int *h_active = nullptr;
-    auto upload_active = [&](const std::vector<int> &idx) -> int {
-        int r;
-        if ((r = ensure(ctx, ctx->sg_active, idx.size() * 4)) || (r = ensure_pinned(ctx, ctx->sgh_active, idx.size() * 4))) return r;
-        // the previous group's copy of the list has been consumed: every group ends with a synchronised download or runs on the same stream
-        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-        h_active = (int *)ctx->sgh_active.p;
-        memcpy(h_active, idx.data(), idx.size() * 4);
-        HIPCHK(ctx, hipMemcpyAsync(ctx->sg_active.p, h_active, idx.size() * 4, hipMemcpyHostToDevice, ctx->stream));
-        return POSE_AMD_OK;
-    };
-    std::vector<int64_t> area_all((size_t)nq, 0);
-    {   // all-matches areas (query_processor.cpp:154-169), groups of up to 1024 queries
-        std::vector<int> all;
-        for (int i = 0; i < nq; ++i) if (qi[(size_t)i].live) all.push_back(i);
-        for (size_t g0 = 0; g0 < all.size(); g0 += 1024) {
-            std::vector<int> idx(all.begin() + g0, all.begin() + std::min(all.size(), g0 + 1024));
-            if ((rc = upload_active(idx))) return rc;
-            const size_t nb = idx.size() * bands_max * 8;
-            if ((rc = ensure(ctx, ctx->sg_allsums, nb)) || (rc = ensure_pinned(ctx, ctx->sgh_allsums, nb))) return rc;
-            seg_launch L{(const seg_query *)ctx->sg_qtab.p, (const int *)ctx->sg_active.p, 0, 0, 0};
-            hipLaunchKernelGGL(k_seg_coverage_all, dim3(1, bands_max, (unsigned)idx.size()), dim3(256), lds_cov, ctx->stream, L, (unsigned long long *)ctx->sg_allsums.p,
-                               bands_max);
-            HIPCHK(ctx, hipGetLastError());
-            if ((rc = download(ctx, ctx->sgh_allsums.p, ctx->sg_allsums.p, nb)) || (rc = pose_amd_synchronize(ctx))) return rc;
-            const unsigned long long *sums = (const unsigned long long *)ctx->sgh_allsums.p;
-            for (size_t a = 0; a < idx.size(); ++a)
-                for (int b = 0; b < qt[idx[a]].bands; ++b) area_all[(size_t)idx[a]] += (int64_t)sums[a * bands_max + b];
-        }
-    }
-
-    // ---- rounds ---------------------------------------------------------------------------------------
-    std::vector<char> done((size_t)nq, 0);
-    std::vector<uint32_t> steps_used((size_t)nq, 0);
     // With early exit most queries end long before the budget does, and every step of a round behind a
     // query's last one is wasted: rounds start short and double.
     uint32_t first_len = 64u, growth = 2u;
@@ -1309,23 +1377,26 @@ static int ransac_batch_segmented(pose_amd_ctx *ctx, int nq, const pose_amd_quer
         unsigned a1 = 0, a2 = 0;
         if (sscanf(e, "%u,%u", &a1, &a2) == 2 && a1 >= 16 && a2 >= 2) { first_len = std::min(a1, 16384u); growth = std::min(a2, 16u); }
     }
+    // bytes of per-hypothesis arrays a pass may use: a round whose list of running queries may be
+    // longer than that is issued as several passes (the later ones usually find the list ended)
+    size_t pass_bytes = (size_t)4 << 30;
+    if (const char *e = getenv("POSE_AMD_SEG_PASS_MB")) pass_bytes = (size_t)std::max(16, atoi(e)) << 20;
+    const int bands_max = b->bands_max;
+
     uint32_t step0 = 0, next_len = early ? first_len : 16384u;
-    const size_t max_slots = (size_t)6 << 20;                // pose slots per launch sequence (about 2 GB of pose data)
     while (step0 < budget) {
         const uint32_t valid = std::min(next_len, budget - step0);
         const int S = (int)((valid + 63) / 64 * 64);
-        bool any = false;
         for (int solver = 0; solver < 2; ++solver) {
+            if (nsolver[solver] == 0) continue;
             const int maxsol = solver ? P4PF_MAXSOL : P3P_MAXSOL;
-            std::vector<int> act;
-            for (int i = 0; i < nq; ++i)
-                if (qi[(size_t)i].live && !done[(size_t)i] && !fallback[(size_t)i] && qi[(size_t)i].maxsol == maxsol) act.push_back(i);
-            const size_t per_group = std::max<size_t>(1, max_slots / ((size_t)S * maxsol));
-            for (size_t g0 = 0; g0 < act.size(); g0 += per_group) {
-                std::vector<int> idx(act.begin() + g0, act.begin() + std::min(act.size(), g0 + per_group));
-                const size_t na = idx.size(), nh = na * S, ns = nh * maxsol;
-                any = true;
-                if ((rc = upload_active(idx))) return rc;
+            hipLaunchKernelGGL(k_seg_compact, dim3(1), dim3(COVSEL_THREADS), 0, ctx->stream, (const seg_query *)b->qtab.p, (const int *)cand_dev[solver],
+                               nsolver[solver], (const unsigned long long *)b->state.p, early ? 1 : 0, active_dev[solver], nact_dev[solver]);
+            const size_t per_hyp = (size_t)maxsol * (96 + 104 + 128 + 4) + 16 + 4 + 4 + (solver ? P4PF_TAIL * 8 + 4 : 0);
+            // after the first round only queries that did not end in it are left: at most all of them
+            const int per_pass = (int)std::max<size_t>(1, std::min<size_t>((size_t)nsolver[solver], std::min<size_t>(32768, pass_bytes / ((size_t)S * per_hyp))));
+            for (int a0 = 0; a0 < nsolver[solver]; a0 += per_pass) {
+                const size_t na = (size_t)std::min(per_pass, nsolver[solver] - a0), nh = na * S, ns = nh * maxsol;
                 if ((rc = ensure(ctx, ctx->sg_samples, nh * 16)) || (rc = ensure(ctx, ctx->sg_sstatus, nh * 4)) || (rc = ensure(ctx, ctx->sg_proj, ns * 96)) ||
                     (rc = ensure(ctx, ctx->sg_pose, ns * 104)) || (rc = ensure(ctx, ctx->sg_projf, ns * 128)) || (rc = ensure(ctx, ctx->sg_nsol, nh * 4)) ||
                     (rc = ensure(ctx, ctx->sg_counts, ns * 4)) || (rc = ensure(ctx, ctx->sg_n, na * 16)) || (rc = ensure(ctx, ctx->sg_list1, na * cap1 * 4)) ||
@@ -1335,15 +1406,15 @@ static int ransac_batch_segmented(pose_amd_ctx *ctx, int nq, const pose_amd_quer
                     (rc = ensure(ctx, ctx->sg_mkeep, na * (cap1 + cap2))))
                     return rc;
                 if (solver && ((rc = ensure(ctx, ctx->sg_arows, nh * P4PF_TAIL * 8)) || (rc = ensure(ctx, ctx->sg_pstatus, nh * 4)))) return rc;
-                seg_launch L{(const seg_query *)ctx->sg_qtab.p, (const int *)ctx->sg_active.p, S, (int)valid, step0};
+                seg_launch L{(const seg_query *)b->qtab.p, (const int *)active_dev[solver], (const int *)nact_dev[solver], a0, S, (int)valid, step0};
                 uint32_t *samples = (uint32_t *)ctx->sg_samples.p;
                 double *proj = (double *)ctx->sg_proj.p, *pose = (double *)ctx->sg_pose.p;
                 float *projf = (float *)ctx->sg_projf.p;
                 int *nsol = (int *)ctx->sg_nsol.p, *counts = (int *)ctx->sg_counts.p;
                 if (advanced)
                     hipLaunchKernelGGL(k_seg_sample_advanced, dim3(cdiv(valid, SAMPLE_ADV_WAVES), (unsigned)na), dim3(64 * SAMPLE_ADV_WAVES),
-                                       (size_t)SAMPLE_ADV_WAVES * std::max(bm_max, 1) * 4, ctx->stream, L, seed, (const double *)ctx->gain.p, samples,
-                                       (int *)ctx->sg_sstatus.p, std::max(bm_max, 1));
+                                       (size_t)SAMPLE_ADV_WAVES * std::max(b->bm_max, 1) * 4, ctx->stream, L, seed, (const double *)ctx->gain.p, samples,
+                                       (int *)ctx->sg_sstatus.p, std::max(b->bm_max, 1));
                 else
                     hipLaunchKernelGGL(k_seg_sample_basic, dim3(cdiv(valid, 256), (unsigned)na), dim3(256), 0, ctx->stream, L, seed, samples);
                 if (solver) {
@@ -1363,66 +1434,80 @@ static int ransac_batch_segmented(pose_amd_ctx *ctx, int nq, const pose_amd_quer
                 while (spb > 8 && (long long)na * cdiv((long long)valid * maxsol, spb) < (ctx->cus ? ctx->cus : 256) * 4) spb >>= 1;
                 hipLaunchKernelGGL(k_seg_score_screen, dim3(cdiv((long long)valid * maxsol, spb), (unsigned)na), dim3(SCORE_THREADS), 0, ctx->stream, L, maxsol,
                                    (const double *)proj, (const float *)projf, (const int *)nsol, prm->eps, counts, spb);
-                seg_cov C{(unsigned long long *)ctx->sg_state.p, (int *)ctx->sg_n.p, (int *)ctx->sg_list1.p, (long long *)ctx->sg_area1.p,
+                seg_cov C{(unsigned long long *)b->state.p, (int *)ctx->sg_n.p, (int *)ctx->sg_list1.p, (long long *)ctx->sg_area1.p,
                           (unsigned long long *)ctx->sg_bands1.p, cap1, (int *)ctx->sg_list2.p, (unsigned long long *)ctx->sg_bands2.p, cap2,
                           (int *)ctx->sg_mslot.p, (long long *)ctx->sg_marea.p, (unsigned char *)ctx->sg_mkeep.p, bands_max};
                 hipLaunchKernelGGL(k_seg_cov_records, dim3((unsigned)na), dim3(COVSEL_THREADS), 0, ctx->stream, L, C, (const int *)counts, (const int *)nsol);
-                hipLaunchKernelGGL(k_seg_coverage, dim3(2, bands_max, (unsigned)na), dim3(256), lds_cov, ctx->stream, L, C, 0, (const double *)proj, prm->eps);
+                hipLaunchKernelGGL(k_seg_coverage, dim3(2, bands_max, (unsigned)na), dim3(256), b->lds_cov, ctx->stream, L, C, 0, (const double *)proj, prm->eps);
                 hipLaunchKernelGGL(k_seg_cov_candidates, dim3((unsigned)na), dim3(COVSEL_THREADS), 0, ctx->stream, L, C, early ? 1 : 0, (const int *)counts,
                                    (const int *)nsol);
-                hipLaunchKernelGGL(k_seg_coverage, dim3(8, bands_max, (unsigned)na), dim3(256), lds_cov, ctx->stream, L, C, 1, (const double *)proj, prm->eps);
+                hipLaunchKernelGGL(k_seg_coverage, dim3(8, bands_max, (unsigned)na), dim3(256), b->lds_cov, ctx->stream, L, C, 1, (const double *)proj, prm->eps);
                 hipLaunchKernelGGL(k_seg_cov_final, dim3((unsigned)na), dim3(COVSEL_THREADS), 0, ctx->stream, L, C, early ? 1 : 0, (const int *)counts,
-                                   (const int *)nsol, (const double *)pose, (const double *)proj);
+                                   (const int *)nsol, (const double *)pose, (const double *)proj, (unsigned long long *)b->totals.p);
                 HIPCHK(ctx, hipGetLastError());
-                if (getenv("POSE_AMD_SEG_STATS")) {          // development aid: list lengths of the group
-                    std::vector<int> nn(na * 4);
-                    HIPCHK(ctx, hipMemcpyAsync(nn.data(), ctx->sg_n.p, na * 16, hipMemcpyDeviceToHost, ctx->stream));
-                    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-                    long long s1 = 0, s2 = 0; int m1 = 0, m2 = 0;
-                    for (size_t a = 0; a < na; ++a) { s1 += nn[4 * a]; s2 += nn[4 * a + 1]; m1 = std::max(m1, nn[4 * a]); m2 = std::max(m2, nn[4 * a + 1]); }
-                    fprintf(stderr, "seg: step0 %u steps %u solver %d queries %zu records %lld (max %d) candidates %lld (max %d)\n", step0, valid, solver, na, s1, m1, s2, m2);
-                }
             }
-        }
-        if (!any) break;
-        // ---- outcome of the round ------------------------------------------------------------------------
-        if ((rc = download(ctx, ctx->sgh_state.p, ctx->sg_state.p, (size_t)nq * 33 * 8)) || (rc = pose_amd_synchronize(ctx))) return rc;
-        const unsigned long long *st = (const unsigned long long *)ctx->sgh_state.p;
-        bool more = false;
-        for (int i = 0; i < nq; ++i) {
-            if (!qi[(size_t)i].live || done[(size_t)i] || fallback[(size_t)i]) continue;
-            const unsigned long long *w = st + (size_t)i * 33;
-            if (w[7]) { fallback[(size_t)i] = 1; continue; }
-            pose_amd_result &r = results[i];
-            const int maxsol = qi[(size_t)i].maxsol;
-            steps_used[(size_t)i] += (uint32_t)w[3];
-            r.poses_scored += w[4];
-            if (w[6] != ~0ull) {
-                const double *pz = (const double *)(w + 8);
-                r.found = 1;
-                r.focal = pz[0];
-                memcpy(r.C, pz + 1, 24);
-                memcpy(r.Rc, pz + 4, 72);
-                r.inliers = (uint32_t)w[1];
-                r.area_fit = (int64_t)w[0];
-                r.best_hyp = step0 + (uint32_t)(w[6] / (unsigned)maxsol);
-                r.best_sol = (uint32_t)(w[6] % (unsigned)maxsol);
-            }
-            if (w[5] || step0 + valid >= budget) done[(size_t)i] = 1;
-            // the loop condition at the start of the next step (basic.cpp:132-133) with the pose kept so far
-            else if (early && r.found && r.inliers >= qt[i].thresh) done[(size_t)i] = 1;
-            else more = true;
         }
         step0 += valid;
         next_len = std::min<uint32_t>(16384u, next_len * growth);
-        if (!more) break;
     }
+    lap("issued");
+    // ---- outcome -------------------------------------------------------------------------------------
+    unsigned long long *out = (unsigned long long *)b->h_out.p;
+    if ((rc = download(ctx, out, b->state.p, (size_t)nq * 33 * 8)) || (rc = download(ctx, out + (size_t)nq * 33, b->totals.p, (size_t)nq * 32)) ||
+        (rc = pose_amd_synchronize(ctx)))
+        return rc;
+    lap("done");
     for (int i = 0; i < nq; ++i) {
-        if (fallback[(size_t)i]) continue;
-        results[i].steps = steps_used[(size_t)i];
-        results[i].area_all = qi[(size_t)i].live ? area_all[(size_t)i] : 0;
+        if (!live[(size_t)i]) continue;
+        const unsigned long long *w = out + (size_t)i * 33, *t = out + (size_t)nq * 33 + (size_t)i * 4;
+        if (w[7]) { fallback[(size_t)i] = 1; continue; }
+        pose_amd_result &r = results[i];
+        r.steps = (uint32_t)t[0];
+        r.poses_scored = t[1];
+        r.area_all = b->area_all[(size_t)i];
+        if (t[2] != 0ull) {
+            const double *pz = (const double *)(w + 8);
+            r.found = 1;
+            r.focal = pz[0];
+            memcpy(r.C, pz + 1, 24);
+            memcpy(r.Rc, pz + 4, 72);
+            r.inliers = (uint32_t)w[1];
+            r.area_fit = (int64_t)w[0];
+            r.best_hyp = (uint32_t)((t[2] >> 8) - 1ull);
+            r.best_sol = (uint32_t)(t[2] & 0xffull);
+        }
     }
     return POSE_AMD_OK;
+}
+
+// The queries of a resident list that the shared launches handed back (fallback[i] set), or all of
+// them (fallback == nullptr), one launch sequence per query on an internal context.
+static int batch_run_per_query(pose_amd_batch *b, const std::vector<char> *fallback, int sample_mode, uint64_t seed, uint32_t budget,
+                               const pose_amd_params *prm, pose_amd_result *results, const char *who)
+{
+    pose_amd_ctx *ctx = b->ctx;
+    pose_amd_ctx *l = nullptr;
+    if (ctx->lanes.empty()) {
+        if (pose_amd_create(ctx->device, &l) != POSE_AMD_OK) return fail(ctx, POSE_AMD_EHIP, "ransac_batch: cannot create an internal stream");
+        l->timing = false;
+        l->lazy_sync = true;
+        ctx->lanes.push_back(l);
+    }
+    l = ctx->lanes[0];
+    const bool lazy = l->lazy_sync;
+    l->lazy_sync = false;
+    int rc = POSE_AMD_OK;
+    for (int i = 0; i < b->nq && !rc; ++i) {
+        if (fallback && !(*fallback)[(size_t)i]) continue;
+        const pose_amd_query &q = b->host_q[(size_t)i];
+        rc = pose_amd_set_query(l, q.n, q.kx, q.ky, q.X, q.Y, q.Z, q.lindex, q.width, q.height, q.focal);
+        if (!rc && sample_mode == POSE_AMD_SAMPLE_ADVANCED) rc = pose_amd_set_camsets(l, q.cam_off, q.cam_ids);
+        if (!rc) rc = pose_amd_sample(l, sample_mode, seed, q.query_id, 0, budget, nullptr);
+        if (!rc) rc = pose_amd_ransac_run(l, prm, &results[i], nullptr, nullptr);
+        if (rc) ctx->err = std::string(who) + ": query " + std::to_string(i) + ": " + l->err;
+    }
+    l->lazy_sync = lazy;
+    return rc;
 }
 
 // ---- many queries -------------------------------------------------------------------------------
@@ -1430,52 +1515,11 @@ static int ransac_batch_segmented(pose_amd_ctx *ctx, int nq, const pose_amd_quer
 // threads, each owning a child context (its own stream and buffers), take queries from a shared
 // counter and run the ordinary per-query sequence on them; while one worker waits for its
 // chunk, the launches of the others keep the device busy.
-int pose_amd_ransac_batch(pose_amd_ctx *ctx, int nq, const pose_amd_query *queries, int sample_mode, uint64_t seed,
-                          uint32_t budget, const pose_amd_params *prm, pose_amd_result *results)
+// One launch sequence per query on worker threads (each with its own stream): inlier-count
+// selection, and everything when POSE_AMD_BATCH=threads.
+static int ransac_batch_threads(pose_amd_ctx *ctx, int nq, const pose_amd_query *queries, int sample_mode, uint64_t seed, uint32_t budget,
+                                const pose_amd_params *prm, pose_amd_result *results)
 {
-    if (!ctx || nq < 0 || (nq && (!queries || !results)) || !prm) return fail(ctx, POSE_AMD_EINVAL, "ransac_batch: bad argument");
-    if (nq == 0) return POSE_AMD_OK;
-    HIPCHK(ctx, hipSetDevice(ctx->device));
-    // The reference's selection (coverage quality) runs many queries per launch; queries that do not
-    // fit that path, and inlier-count selection, take one launch sequence per query on worker threads.
-    static const bool seg_off = getenv("POSE_AMD_BATCH") && strcmp(getenv("POSE_AMD_BATCH"), "threads") == 0;
-    std::vector<char> fallback;
-    std::vector<pose_amd_query> fb_queries;
-    std::vector<int> fb_index;
-    if (!seg_off && prm->select_mode == POSE_AMD_SELECT_COVERAGE && prm->eps > 0 && prm->inlier_divisor != 0 &&
-        (sample_mode == POSE_AMD_SAMPLE_BASIC || sample_mode == POSE_AMD_SAMPLE_ADVANCED)) {
-        const int rc = ransac_batch_segmented(ctx, nq, queries, sample_mode, seed, budget, prm, results, fallback);
-        if (rc) return rc;
-        for (int i = 0; i < nq; ++i) if (fallback[(size_t)i]) { fb_queries.push_back(queries[i]); fb_index.push_back(i); }
-        if (fb_queries.empty()) return POSE_AMD_OK;
-        std::vector<pose_amd_result> fb_results(fb_queries.size());
-        const pose_amd_params p2 = *prm;
-        // the leftover queries, one launch sequence each
-        int rc2 = POSE_AMD_OK;
-        {
-            pose_amd_ctx *l = nullptr;
-            if (ctx->lanes.empty()) {
-                if (pose_amd_create(ctx->device, &l) != POSE_AMD_OK) return fail(ctx, POSE_AMD_EHIP, "ransac_batch: cannot create an internal stream");
-                l->timing = false;
-                l->lazy_sync = true;
-                ctx->lanes.push_back(l);
-            }
-            l = ctx->lanes[0];
-            const bool lazy = l->lazy_sync;
-            l->lazy_sync = false;
-            for (size_t k = 0; k < fb_queries.size() && !rc2; ++k) {
-                const pose_amd_query &q = fb_queries[k];
-                rc2 = pose_amd_set_query(l, q.n, q.kx, q.ky, q.X, q.Y, q.Z, q.lindex, q.width, q.height, q.focal);
-                if (!rc2 && sample_mode == POSE_AMD_SAMPLE_ADVANCED) rc2 = pose_amd_set_camsets(l, q.cam_off, q.cam_ids);
-                if (!rc2) rc2 = pose_amd_sample(l, sample_mode, seed, q.query_id, 0, budget, nullptr);
-                if (!rc2) rc2 = pose_amd_ransac_run(l, &p2, &fb_results[k], nullptr, nullptr);
-                if (rc2) ctx->err = "ransac_batch: query " + std::to_string(fb_index[k]) + ": " + l->err;
-                else results[fb_index[k]] = fb_results[k];
-            }
-            l->lazy_sync = lazy;
-        }
-        return rc2;
-    }
     int nl = 8;
     if (const char *e = getenv("POSE_AMD_BATCH_LANES")) nl = std::max(1, std::min(64, atoi(e)));
     nl = std::min(nl, nq);
@@ -1510,6 +1554,75 @@ int pose_amd_ransac_batch(pose_amd_ctx *ctx, int nq, const pose_amd_query *queri
     worker(ctx->lanes[0]);
     for (std::thread &t : pool) t.join();
     return status.load();
+}
+
+// The reference's selection (coverage quality) runs many queries per launch; inlier-count selection
+// and POSE_AMD_BATCH=threads take one launch sequence per query on worker threads.
+static bool batch_shares_launches(int sample_mode, const pose_amd_params *prm)
+{
+    static const bool off = getenv("POSE_AMD_BATCH") && strcmp(getenv("POSE_AMD_BATCH"), "threads") == 0;
+    return !off && prm->select_mode == POSE_AMD_SELECT_COVERAGE && prm->eps > 0 && prm->inlier_divisor != 0 &&
+           (sample_mode == POSE_AMD_SAMPLE_BASIC || sample_mode == POSE_AMD_SAMPLE_ADVANCED);
+}
+
+static int batch_run(pose_amd_batch *b, int sample_mode, uint64_t seed, uint32_t budget, const pose_amd_params *prm, pose_amd_result *results, const char *who)
+{
+    pose_amd_ctx *ctx = b->ctx;
+    if (sample_mode == POSE_AMD_SAMPLE_ADVANCED && !b->has_cams)
+        return fail(ctx, POSE_AMD_ESTATE, (std::string(who) + ": advanced sampling needs camera sets").c_str());
+    if (!batch_shares_launches(sample_mode, prm)) return ransac_batch_threads(ctx, b->nq, b->host_q.data(), sample_mode, seed, budget, prm, results);
+    std::vector<char> fallback;
+    int rc = batch_run_segmented(b, sample_mode, seed, budget, prm, results, fallback);
+    if (rc) return rc;
+    bool any = false;
+    for (char f : fallback) any = any || f;
+    return any ? batch_run_per_query(b, &fallback, sample_mode, seed, budget, prm, results, who) : POSE_AMD_OK;
+}
+
+int pose_amd_ransac_batch(pose_amd_ctx *ctx, int nq, const pose_amd_query *queries, int sample_mode, uint64_t seed,
+                          uint32_t budget, const pose_amd_params *prm, pose_amd_result *results)
+{
+    if (!ctx || nq < 0 || (nq && (!queries || !results)) || !prm) return fail(ctx, POSE_AMD_EINVAL, "ransac_batch: bad argument");
+    if (nq == 0) return POSE_AMD_OK;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (!batch_shares_launches(sample_mode, prm)) return ransac_batch_threads(ctx, nq, queries, sample_mode, seed, budget, prm, results);
+    if (!ctx->own_batch) ctx->own_batch = new pose_amd_batch();          // its buffers are reused from call to call
+    const int rc = batch_fill(ctx, ctx->own_batch, nq, queries, sample_mode == POSE_AMD_SAMPLE_ADVANCED, "ransac_batch");
+    return rc ? rc : batch_run(ctx->own_batch, sample_mode, seed, budget, prm, results, "ransac_batch");
+}
+
+int pose_amd_batch_create(pose_amd_ctx *ctx, int nq, const pose_amd_query *queries, int with_camsets, pose_amd_batch **out)
+{
+    if (!ctx || !out || nq < 0 || (nq && !queries)) return fail(ctx, POSE_AMD_EINVAL, "batch_create: bad argument");
+    *out = nullptr;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    pose_amd_batch *b = new pose_amd_batch();
+    b->ctx = ctx;
+    if (nq > 0) {
+        const int rc = batch_fill(ctx, b, nq, queries, with_camsets != 0, "batch_create");
+        if (rc) { batch_free(b); return rc; }
+    }
+    *out = b;
+    return POSE_AMD_OK;
+}
+
+int pose_amd_batch_size(const pose_amd_batch *b) { return b ? b->nq : 0; }
+
+int pose_amd_batch_run(pose_amd_batch *b, int sample_mode, uint64_t seed, uint32_t budget, const pose_amd_params *prm, pose_amd_result *results)
+{
+    if (!b || !b->ctx) return POSE_AMD_EINVAL;
+    pose_amd_ctx *ctx = b->ctx;
+    if (!prm || (b->nq && !results)) return fail(ctx, POSE_AMD_EINVAL, "batch_run: bad argument");
+    if (b->nq == 0) return POSE_AMD_OK;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    return batch_run(b, sample_mode, seed, budget, prm, results, "batch_run");
+}
+
+void pose_amd_batch_destroy(pose_amd_batch *b)
+{
+    if (!b) return;
+    if (b->ctx) (void)hipSetDevice(b->ctx->device);
+    batch_free(b);
 }
 
 // ---- several GPUs from one host process ------------------------------------------------------------

@@ -336,6 +336,36 @@ def test_multi_query_launches_hand_crowded_queries_to_the_per_query_path(ctx, mo
         assert np.array_equal(a["C"], b["C"]) and np.array_equal(a["Rc"], b["Rc"]) and a["focal"] == b["focal"]
 
 
+def test_resident_query_list_runs_any_number_of_times(ctx, monkeypatch):
+    """pose_amd_batch_create / _run / _destroy: the list is uploaded once and then run with
+    different samplers, selections, budgets and seeds; every run returns what pose_amd_ransac_batch
+    returns for the same arguments.  A small per-pass memory bound forces rounds of several passes."""
+    queries = mixed_queries()
+    rb = ctx.resident_batch(queries, with_camsets=True)
+    assert rb.nq == len(queries)
+    runs = [dict(sample_mode=SAMPLE_BASIC, seed=5, budget=2500, select_mode=SELECT_COVERAGE, early_exit=True),
+            dict(sample_mode=SAMPLE_ADVANCED, seed=6, budget=100, select_mode=SELECT_COVERAGE, early_exit=False),
+            dict(sample_mode=SAMPLE_BASIC, seed=7, budget=700, select_mode=SELECT_INLIERS, early_exit=False),
+            dict(sample_mode=SAMPLE_BASIC, seed=5, budget=2500, select_mode=SELECT_COVERAGE, early_exit=True)]
+    for i, kw in enumerate(runs):
+        if i == 3:
+            monkeypatch.setenv("POSE_AMD_SEG_PASS_MB", "16")
+        got = rb.run(**kw)
+        want = ctx.ransac_batch(queries, kw["sample_mode"], seed=kw["seed"], budget=kw["budget"], select_mode=kw["select_mode"], early_exit=kw["early_exit"])
+        for a, b in zip(want, got):
+            for k in RESULT_KEYS:
+                assert a[k] == b[k], (i, k)
+            assert np.array_equal(a["C"], b["C"]) and np.array_equal(a["Rc"], b["Rc"]) and a["focal"] == b["focal"]
+    rb.close()
+    plain = ctx.resident_batch([dict(q, cam_off=None, cam_ids=None) for q in queries[:2]])
+    with pytest.raises(Exception, match="camera sets"):
+        plain.run(sample_mode=SAMPLE_ADVANCED, budget=100)
+    plain.close()
+    empty = ctx.resident_batch([])
+    assert empty.run() == []
+    empty.close()
+
+
 def test_multi_query_launches_report_bad_queries(ctx):
     queries = mixed_queries()[:3]
     bad = dict(queries[1]); bad["kx"] = bad["kx"][:2]; bad["ky"] = bad["ky"][:2]; bad["X"] = bad["X"][:2]; bad["Y"] = bad["Y"][:2]; bad["Z"] = bad["Z"][:2]
