@@ -172,7 +172,7 @@ __global__ __launch_bounds__(256) void k_seg_coverage(seg_launch L, seg_cov C, i
 {
     extern __shared__ unsigned int s_bm[];
     __shared__ unsigned long long s_sum[256];
-    __shared__ int s_any;
+    __shared__ int s_any, s_cnt;
     const int a = blockIdx.z;
     if (!seg_live(L, a)) return;
     const seg_query &sq = seg_of(L, a);
@@ -182,9 +182,12 @@ __global__ __launch_bounds__(256) void k_seg_coverage(seg_launch L, seg_cov C, i
     const int *list = which ? C.list2 + (size_t)a * C.cap2 : C.list1 + (size_t)a * C.cap1;
     unsigned long long *sums = which ? C.bands2 + (size_t)a * C.cap2 * C.bands_max : C.bands1 + (size_t)a * C.cap1 * C.bands_max;
     const double *pq = proj + (size_t)a * L.S * sq.maxsol * 12;
+    if (sq.separable) {
+        coverage_band_poses(sq.q, blockIdx.x, gridDim.x, n, pq, list, eps, sq.band_rows, sq.wpr, sums, s_bm, s_sum, s_any, s_cnt, blockIdx.y, sq.bands);
+        return;
+    }
     for (int pose = blockIdx.x; pose < n; pose += gridDim.x) {
-        if (sq.separable) coverage_band(sq.q, pose, pq, list, eps, 0, sq.band_rows, sq.wpr, sums, s_bm, s_sum, s_any, blockIdx.y, sq.bands);
-        else coverage_band_direct(sq.q, pose, pq, list, eps, 0, sq.band_rows, sq.wpr, sums, s_bm, s_sum, blockIdx.y, sq.bands);
+        coverage_band_direct(sq.q, pose, pq, list, eps, 0, sq.band_rows, sq.wpr, sums, s_bm, s_sum, blockIdx.y, sq.bands);
         __syncthreads();
     }
 }

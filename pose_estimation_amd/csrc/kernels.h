@@ -903,6 +903,65 @@ __global__ __launch_bounds__(SCORE_THREADS) __attribute__((amdgpu_waves_per_eu(6
 // that the 2h extra rows of a band do not fit the LDS.
 // ------------------------------------------------------------------------------------------
 constexpr int COV_UNROLL = 8;
+// The painted rows Hm[nh][words_per_row] of one band are complete: unions of aligned groups of
+// eight rows into G, then every output row as the union of the 2h painted rows above it, bits
+// counted.  Ends with the band's sum in *out (written by thread 0; callers synchronise before they
+// reuse the LDS).
+__device__ __forceinline__ void coverage_band_count(const query_dev &q, int row0, int row1, int h, int nh, int ng, int words_per_row,
+                                                    unsigned int *Hm, unsigned int *G, unsigned long long *s_sum, unsigned long long *out)
+{
+    const int tid = threadIdx.x;
+    for (int t = tid; t < ng * words_per_row; t += blockDim.x) {
+        const int g = t / words_per_row, c = t - g * words_per_row;
+        unsigned int v = 0;
+        for (int yy = 8 * g; yy < min(nh, 8 * g + 8); ++yy) v |= Hm[yy * words_per_row + c];
+        G[t] = v;
+    }
+    __syncthreads();
+    // Output row row0 + rr is the union of painted rows rr .. rr + 2h - 1; the last image row is
+    // never covered.  A thread forms the eight output rows rr = 8k .. 8k + 7 of one column word
+    // together: with 2h = 8m + e their windows share the whole groups k + 1 .. k + m - 1, begin
+    // with a suffix of group k and end with the first e + j rows from row 8 (k + m) on.
+    const int rows_out = min(row1, q.height - 1) - row0;
+    const int m = (2 * h) >> 3, e = (2 * h) & 7;
+    unsigned long long a = 0;
+    for (int t = tid; t < ((rows_out + 7) >> 3) * words_per_row; t += blockDim.x) {
+        const int k = t / words_per_row, c = t - k * words_per_row;
+        if (m == 0) {                                        // windows shorter than a group: row by row
+            for (int j = 0; j < 8 && 8 * k + j < rows_out; ++j) {
+                unsigned int v = 0;
+                for (int yy = 8 * k + j; yy < 8 * k + j + e; ++yy) v |= Hm[yy * words_per_row + c];
+                a += __popc(v);
+            }
+            continue;
+        }
+        unsigned int suf[8];
+        unsigned int acc = 0;
+#pragma unroll
+        for (int j = 7; j >= 0; --j) {
+            const int yy = 8 * k + j;
+            if (yy < nh) acc |= Hm[yy * words_per_row + c];
+            suf[j] = acc;
+        }
+        unsigned int common = 0;
+        for (int g = k + 1; g < k + m; ++g) common |= G[g * words_per_row + c];   // g < ng: 8 g + 7 < 8 k + 2 h <= nh
+        const int tail0 = 8 * (k + m);
+        unsigned int pre = 0;
+        for (int i = 0; i < e; ++i) if (tail0 + i < nh) pre |= Hm[(tail0 + i) * words_per_row + c];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if (8 * k + j < rows_out) a += __popc(suf[j] | common | pre);
+            const int yy = tail0 + e + j;
+            if (yy < nh) pre |= Hm[yy * words_per_row + c];
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o);
+    if ((tid & 63) == 0) s_sum[tid >> 6] = a;
+    __syncthreads();
+    if (tid == 0) *out = s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3];
+}
+
 // One (pose, band) of k_coverage by the whole block; every early return is taken by all threads.
 __device__ __forceinline__ void coverage_band(const query_dev &q, int pose, const double *__restrict__ proj, const int *__restrict__ slots,
                                               double eps, int all_matches, int band_rows, int words_per_row,
@@ -963,55 +1022,119 @@ __device__ __forceinline__ void coverage_band(const query_dev &q, int pose, cons
     }
     __syncthreads();
     if (!s_any) { if (tid == 0) *out = 0ull; return; }       // no inlier near this band
-    for (int t = tid; t < ng * words_per_row; t += blockDim.x) {
-        const int g = t / words_per_row, c = t - g * words_per_row;
-        unsigned int v = 0;
-        for (int yy = 8 * g; yy < min(nh, 8 * g + 8); ++yy) v |= Hm[yy * words_per_row + c];
-        G[t] = v;
+    coverage_band_count(q, row0, row1, h, nh, ng, words_per_row, Hm, G, s_sum, out);
+}
+
+constexpr int COV_KEEP = 4;            // correspondences near the band a thread keeps in registers
+
+// The poses first, first + stride, ... (< nposes) of one band by the whole block.  Which boxes can
+// touch the band depends on the keypoints only, not on the pose: those correspondences are found
+// once (through a staging list in the bitmap's LDS, so that they spread evenly over the threads)
+// and stay in registers; per pose the block clears the bitmap, tests and paints them and counts.
+// Without this every (pose, band) read all n correspondences again, which made a launch over
+// many candidate poses of many queries a stream of second-level-cache reads.  When more
+// correspondences lie near the band than the registers hold, the poses are done one by one
+// with coverage_band.  Every early return is taken by all threads.
+__device__ __forceinline__ void coverage_band_poses(const query_dev &q, int first, int stride, int nposes, const double *__restrict__ proj,
+                                                    const int *__restrict__ slots, double eps, int band_rows, int words_per_row,
+                                                    unsigned long long *__restrict__ band_sums, unsigned int *s_bm, unsigned long long *s_sum,
+                                                    int &s_any, int &s_cnt, int band, int nbands)
+{
+    const int tid = threadIdx.x;
+    if (first >= nposes) return;
+    const int row0 = band * band_rows, row1 = min(q.height, row0 + band_rows);
+    const int cover = (int)ceilf((float)q.width / 20.0f), h = cover / 2;
+    if (h == 0) {                                            // every box is empty
+        for (int pose = first + tid * stride; pose < nposes; pose += stride * (int)blockDim.x) band_sums[(size_t)pose * nbands + band] = 0ull;
+        return;
     }
+    const int nh = (row1 - row0) + 2 * h - 1;
+    const int ng = (nh + 7) >> 3;
+    const int y_base = row0 - h + 1;
+    const int lds_words = (nh + ng) * words_per_row;
+    const int cap = min(COV_KEEP * (int)blockDim.x, lds_words / 5);
+    unsigned int *Hm = s_bm, *G = s_bm + nh * words_per_row;
+    float *stage = reinterpret_cast<float *>(s_bm);          // [5][cap]: kx, ky, X, Y, Z
+    if (tid == 0) s_cnt = 0;
     __syncthreads();
-    // Output row row0 + rr is the union of painted rows rr .. rr + 2h - 1; the last image row is
-    // never covered.  A thread forms the eight output rows rr = 8k .. 8k + 7 of one column word
-    // together: with 2h = 8m + e their windows share the whole groups k + 1 .. k + m - 1, begin
-    // with a suffix of group k and end with the first e + j rows from row 8 (k + m) on.
-    const int rows_out = min(row1, q.height - 1) - row0;
-    const int m = (2 * h) >> 3, e = (2 * h) & 7;
-    unsigned long long a = 0;
-    for (int t = tid; t < ((rows_out + 7) >> 3) * words_per_row; t += blockDim.x) {
-        const int k = t / words_per_row, c = t - k * words_per_row;
-        if (m == 0) {                                        // windows shorter than a group: row by row
-            for (int j = 0; j < 8 && 8 * k + j < rows_out; ++j) {
-                unsigned int v = 0;
-                for (int yy = 8 * k + j; yy < 8 * k + j + e; ++yy) v |= Hm[yy * words_per_row + c];
-                a += __popc(v);
+    for (int i0 = tid; i0 < q.n; i0 += COV_UNROLL * blockDim.x) {
+        float kxs[COV_UNROLL], kys[COV_UNROLL];
+#pragma unroll
+        for (int k = 0; k < COV_UNROLL; ++k) {
+            const int i = min(i0 + k * (int)blockDim.x, q.n - 1);
+            kxs[k] = q.kx[i]; kys[k] = q.ky[i];
+        }
+#pragma unroll
+        for (int k = 0; k < COV_UNROLL; ++k) {
+            const int i = i0 + k * (int)blockDim.x;
+            if (i >= q.n) break;
+            const int x = (int)rintf(kxs[k]), y = (int)rintf(kys[k]);
+            const int sx = max(0, min(x - h, q.width - 1)), sy = max(0, min(y - h, q.height - 1));
+            const int ex = max(0, min(x + h, q.width - 1)), ey = max(0, min(y + h, q.height - 1));
+            if (!(sy < ey && sx < ex)) continue;
+            const int yy = y - y_base;
+            if (yy < 0 || yy >= nh) continue;                    // the box does not touch this band
+            const int pos = atomicAdd(&s_cnt, 1);
+            if (pos < cap) {
+                stage[pos] = kxs[k]; stage[cap + pos] = kys[k];
+                stage[2 * cap + pos] = q.X[i]; stage[3 * cap + pos] = q.Y[i]; stage[4 * cap + pos] = q.Z[i];
             }
-            continue;
-        }
-        unsigned int suf[8];
-        unsigned int acc = 0;
-#pragma unroll
-        for (int j = 7; j >= 0; --j) {
-            const int yy = 8 * k + j;
-            if (yy < nh) acc |= Hm[yy * words_per_row + c];
-            suf[j] = acc;
-        }
-        unsigned int common = 0;
-        for (int g = k + 1; g < k + m; ++g) common |= G[g * words_per_row + c];   // g < ng: 8 g + 7 < 8 k + 2 h <= nh
-        const int tail0 = 8 * (k + m);
-        unsigned int pre = 0;
-        for (int i = 0; i < e; ++i) if (tail0 + i < nh) pre |= Hm[(tail0 + i) * words_per_row + c];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            if (8 * k + j < rows_out) a += __popc(suf[j] | common | pre);
-            const int yy = tail0 + e + j;
-            if (yy < nh) pre |= Hm[yy * words_per_row + c];
         }
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o);
-    if ((tid & 63) == 0) s_sum[tid >> 6] = a;
     __syncthreads();
-    if (tid == 0) *out = s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3];
+    const int cnt = s_cnt;
+    if (cnt > cap) {                                         // block-uniform
+        for (int pose = first; pose < nposes; pose += stride) {
+            __syncthreads();
+            coverage_band(q, pose, proj, slots, eps, 0, band_rows, words_per_row, band_sums, s_bm, s_sum, s_any, band, nbands);
+        }
+        return;
+    }
+    float rkx[COV_KEEP], rky[COV_KEEP], rX[COV_KEEP], rY[COV_KEEP], rZ[COV_KEEP];
+#pragma unroll
+    for (int k = 0; k < COV_KEEP; ++k) {
+        const int e = min(tid + k * (int)blockDim.x, max(cnt - 1, 0));
+        rkx[k] = stage[e]; rky[k] = stage[cap + e]; rX[k] = stage[2 * cap + e]; rY[k] = stage[3 * cap + e]; rZ[k] = stage[4 * cap + e];
+    }
+    const double hw = (double)q.width / 2.0, hh = (double)q.height / 2.0;
+    for (int pose = first; pose < nposes; pose += stride) {
+        __syncthreads();                                     // staging list / the previous pose's bitmap and sums are no longer read
+        unsigned long long *out = band_sums + (size_t)pose * nbands + band;
+        {
+            uint4 *v = reinterpret_cast<uint4 *>(s_bm);
+            for (int i = tid; i < lds_words / 4; i += blockDim.x) v[i] = make_uint4(0u, 0u, 0u, 0u);
+            for (int i = (lds_words & ~3) + tid; i < lds_words; i += blockDim.x) s_bm[i] = 0u;
+        }
+        if (tid == 0) s_any = 0;
+        __syncthreads();
+        const double *P = proj + (size_t)(slots ? slots[pose] : pose) * 12;
+#pragma unroll
+        for (int k = 0; k < COV_KEEP; ++k) {
+            if (tid + k * (int)blockDim.x >= cnt) break;
+            const double X = rX[k], Y = rY[k], Z = rZ[k];
+            const double u = -((double)rkx[k] - hw), v = -((double)rky[k] - hh);
+            const double px = fma(P[0], X, fma(P[1], Y, fma(P[2], Z, P[3])));
+            const double py = fma(P[4], X, fma(P[5], Y, fma(P[6], Z, P[7])));
+            const double pz = fma(P[8], X, fma(P[9], Y, fma(P[10], Z, P[11])));
+            const double rx = fma(u, pz, -px), ry = fma(v, pz, -py);
+            const double te = eps * pz;
+            if (!(fma(ry, ry, rx * rx) < te * te)) continue;
+            const int x = (int)rintf(rkx[k]), y = (int)rintf(rky[k]);
+            const int sx = max(0, min(x - h, q.width - 1)), ex = max(0, min(x + h, q.width - 1));
+            const int yy = y - y_base;
+            const int w0 = sx >> 5, w1 = (ex - 1) >> 5;
+            for (int w = w0; w <= w1; ++w) {
+                unsigned int bits = 0xFFFFFFFFu;
+                if (w == w0) bits &= 0xFFFFFFFFu << (sx & 31);
+                if (w == w1) bits &= 0xFFFFFFFFu >> (31 - ((ex - 1) & 31));
+                atomicOr(&Hm[yy * words_per_row + w], bits);
+            }
+            s_any = 1;
+        }
+        __syncthreads();
+        if (!s_any) { if (tid == 0) *out = 0ull; continue; }     // no inlier near this band (block-uniform)
+        coverage_band_count(q, row0, row1, h, nh, ng, words_per_row, Hm, G, s_sum, out);
+    }
 }
 
 // nposes_dev, when given, holds the number of poses (a list built on the device); the blocks of
@@ -1022,8 +1145,12 @@ __global__ __launch_bounds__(256) void k_coverage(query_dev q, int nposes, const
 {
     extern __shared__ unsigned int s_bm[];                   // nh painted rows, then ng rows of group unions
     __shared__ unsigned long long s_sum[4];
-    __shared__ int s_any;
+    __shared__ int s_any, s_cnt;
     const int n = nposes_dev ? *nposes_dev : nposes;
+    if (!all_matches && n > (int)gridDim.x) {                // some block has several poses: share the scan of the correspondences
+        coverage_band_poses(q, blockIdx.x, gridDim.x, n, proj, slots, eps, band_rows, words_per_row, band_sums, s_bm, s_sum, s_any, s_cnt, blockIdx.y, gridDim.y);
+        return;
+    }
     for (int pose = blockIdx.x; pose < n; pose += gridDim.x) {
         coverage_band(q, pose, proj, slots, eps, all_matches, band_rows, words_per_row, band_sums, s_bm, s_sum, s_any, blockIdx.y, gridDim.y);
         __syncthreads();

@@ -1382,6 +1382,13 @@ static int batch_run_segmented(pose_amd_batch *b, int sample_mode, uint64_t seed
     size_t pass_bytes = (size_t)4 << 30;
     if (const char *e = getenv("POSE_AMD_SEG_PASS_MB")) pass_bytes = (size_t)std::max(16, atoi(e)) << 20;
     const int bands_max = b->bands_max;
+    // blocks per (query, band) of the two coverage launches of a pass (records, candidates): every block
+    // scans the query's correspondences once, so few blocks with several poses each
+    int cov_blocks[2] = {1, 4};
+    if (const char *e = getenv("POSE_AMD_SEG_COV_BLOCKS")) {
+        int a1 = 0, a2 = 0;
+        if (sscanf(e, "%d,%d", &a1, &a2) == 2 && a1 > 0 && a2 > 0) { cov_blocks[0] = std::min(a1, 64); cov_blocks[1] = std::min(a2, 64); }
+    }
 
     uint32_t step0 = 0, next_len = early ? first_len : 16384u;
     while (step0 < budget) {
@@ -1438,13 +1445,26 @@ static int batch_run_segmented(pose_amd_batch *b, int sample_mode, uint64_t seed
                           (unsigned long long *)ctx->sg_bands1.p, cap1, (int *)ctx->sg_list2.p, (unsigned long long *)ctx->sg_bands2.p, cap2,
                           (int *)ctx->sg_mslot.p, (long long *)ctx->sg_marea.p, (unsigned char *)ctx->sg_mkeep.p, bands_max};
                 hipLaunchKernelGGL(k_seg_cov_records, dim3((unsigned)na), dim3(COVSEL_THREADS), 0, ctx->stream, L, C, (const int *)counts, (const int *)nsol);
-                hipLaunchKernelGGL(k_seg_coverage, dim3(2, bands_max, (unsigned)na), dim3(256), b->lds_cov, ctx->stream, L, C, 0, (const double *)proj, prm->eps);
+                hipLaunchKernelGGL(k_seg_coverage, dim3(cov_blocks[0], bands_max, (unsigned)na), dim3(256), b->lds_cov, ctx->stream, L, C, 0, (const double *)proj, prm->eps);
                 hipLaunchKernelGGL(k_seg_cov_candidates, dim3((unsigned)na), dim3(COVSEL_THREADS), 0, ctx->stream, L, C, early ? 1 : 0, (const int *)counts,
                                    (const int *)nsol);
-                hipLaunchKernelGGL(k_seg_coverage, dim3(8, bands_max, (unsigned)na), dim3(256), b->lds_cov, ctx->stream, L, C, 1, (const double *)proj, prm->eps);
+                hipLaunchKernelGGL(k_seg_coverage, dim3(cov_blocks[1], bands_max, (unsigned)na), dim3(256), b->lds_cov, ctx->stream, L, C, 1, (const double *)proj, prm->eps);
                 hipLaunchKernelGGL(k_seg_cov_final, dim3((unsigned)na), dim3(COVSEL_THREADS), 0, ctx->stream, L, C, early ? 1 : 0, (const int *)counts,
                                    (const int *)nsol, (const double *)pose, (const double *)proj, (unsigned long long *)b->totals.p);
                 HIPCHK(ctx, hipGetLastError());
+                if (stats) {                                   // list lengths of the pass (this waits for the device)
+                    std::vector<int> nn(na * 4, 0);
+                    int nact = 0;
+                    HIPCHK(ctx, hipMemcpyAsync(nn.data(), ctx->sg_n.p, na * 16, hipMemcpyDeviceToHost, ctx->stream));
+                    HIPCHK(ctx, hipMemcpyAsync(&nact, nact_dev[solver], 4, hipMemcpyDeviceToHost, ctx->stream));
+                    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+                    long long s1 = 0, s2 = 0;
+                    int m1 = 0, m2 = 0;
+                    const int lim = std::max(0, std::min((int)na, nact - a0));
+                    for (int a = 0; a < lim; ++a) { s1 += nn[4 * a]; s2 += nn[4 * a + 1]; m1 = std::max(m1, nn[4 * a]); m2 = std::max(m2, nn[4 * a + 1]); }
+                    fprintf(stderr, "seg: step0 %u steps %u solver %d running %d records %lld (max %d) candidates %lld (max %d)\n", step0, valid, solver, lim, s1, m1,
+                            s2, m2);
+                }
             }
         }
         step0 += valid;
