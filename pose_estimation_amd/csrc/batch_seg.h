@@ -183,7 +183,7 @@ __global__ __launch_bounds__(256) void k_seg_coverage(seg_launch L, seg_cov C, i
     unsigned long long *sums = which ? C.bands2 + (size_t)a * C.cap2 * C.bands_max : C.bands1 + (size_t)a * C.cap1 * C.bands_max;
     const double *pq = proj + (size_t)a * L.S * sq.maxsol * 12;
     if (sq.separable) {
-        coverage_band_poses(sq.q, blockIdx.x, gridDim.x, n, pq, list, eps, sq.band_rows, sq.wpr, sums, s_bm, s_sum, s_any, s_cnt, blockIdx.y, sq.bands);
+        coverage_band_poses<8>(sq.q, blockIdx.x, gridDim.x, n, pq, list, eps, sq.band_rows, sq.wpr, sums, s_bm, s_sum, s_any, s_cnt, blockIdx.y, sq.bands);
         return;
     }
     for (int pose = blockIdx.x; pose < n; pose += gridDim.x) {

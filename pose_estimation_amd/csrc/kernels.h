@@ -911,10 +911,17 @@ __device__ __forceinline__ void coverage_band_count(const query_dev &q, int row0
                                                     unsigned int *Hm, unsigned int *G, unsigned long long *s_sum, unsigned long long *out)
 {
     const int tid = threadIdx.x;
+    // All reads of an item are issued before the first is used (clamped addresses, validity applied
+    // afterwards): with loops whose trip count the compiler does not know every read waited for the
+    // one before it, and a block spent its time on LDS round trips.
     for (int t = tid; t < ng * words_per_row; t += blockDim.x) {
         const int g = t / words_per_row, c = t - g * words_per_row;
+        unsigned int r[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r[j] = Hm[min(8 * g + j, nh - 1) * words_per_row + c];
         unsigned int v = 0;
-        for (int yy = 8 * g; yy < min(nh, 8 * g + 8); ++yy) v |= Hm[yy * words_per_row + c];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v |= 8 * g + j < nh ? r[j] : 0u;
         G[t] = v;
     }
     __syncthreads();
@@ -935,24 +942,35 @@ __device__ __forceinline__ void coverage_band_count(const query_dev &q, int row0
             }
             continue;
         }
+        const int tail0 = 8 * (k + m);
+        unsigned int hv[8], tv[7], uv[8];                    // group k; rows tail0 .. tail0 + 6; rows tail0 + e .. tail0 + e + 7
+#pragma unroll
+        for (int j = 0; j < 8; ++j) hv[j] = Hm[min(8 * k + j, nh - 1) * words_per_row + c];
+#pragma unroll
+        for (int i = 0; i < 7; ++i) tv[i] = Hm[min(tail0 + i, nh - 1) * words_per_row + c];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) uv[j] = Hm[min(tail0 + e + j, nh - 1) * words_per_row + c];
+        unsigned int common = 0;
+        for (int g0 = k + 1; g0 < k + m; g0 += 4) {          // g < ng: 8 g + 7 < 8 k + 2 h <= nh
+            unsigned int gv[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) gv[j] = G[min(g0 + j, k + m - 1) * words_per_row + c];
+            common |= gv[0] | gv[1] | gv[2] | gv[3];         // a clamped read repeats a group of the window
+        }
         unsigned int suf[8];
         unsigned int acc = 0;
 #pragma unroll
         for (int j = 7; j >= 0; --j) {
-            const int yy = 8 * k + j;
-            if (yy < nh) acc |= Hm[yy * words_per_row + c];
+            if (8 * k + j < nh) acc |= hv[j];
             suf[j] = acc;
         }
-        unsigned int common = 0;
-        for (int g = k + 1; g < k + m; ++g) common |= G[g * words_per_row + c];   // g < ng: 8 g + 7 < 8 k + 2 h <= nh
-        const int tail0 = 8 * (k + m);
         unsigned int pre = 0;
-        for (int i = 0; i < e; ++i) if (tail0 + i < nh) pre |= Hm[(tail0 + i) * words_per_row + c];
+#pragma unroll
+        for (int i = 0; i < 7; ++i) if (i < e && tail0 + i < nh) pre |= tv[i];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             if (8 * k + j < rows_out) a += __popc(suf[j] | common | pre);
-            const int yy = tail0 + e + j;
-            if (yy < nh) pre |= Hm[yy * words_per_row + c];
+            if (tail0 + e + j < nh) pre |= uv[j];
         }
     }
 #pragma unroll
@@ -1025,7 +1043,8 @@ __device__ __forceinline__ void coverage_band(const query_dev &q, int pose, cons
     coverage_band_count(q, row0, row1, h, nh, ng, words_per_row, Hm, G, s_sum, out);
 }
 
-constexpr int COV_KEEP = 4;            // correspondences near the band a thread keeps in registers
+// COV_KEEP: correspondences near the band a thread keeps in registers (4 for the sixteen thin bands
+// of the per-query launches, 8 for the thick bands of the multi-query launches)
 
 // The poses first, first + stride, ... (< nposes) of one band by the whole block.  Which boxes can
 // touch the band depends on the keypoints only, not on the pose: those correspondences are found
@@ -1035,6 +1054,7 @@ constexpr int COV_KEEP = 4;            // correspondences near the band a thread
 // many candidate poses of many queries a stream of second-level-cache reads.  When more
 // correspondences lie near the band than the registers hold, the poses are done one by one
 // with coverage_band.  Every early return is taken by all threads.
+template <int COV_KEEP>
 __device__ __forceinline__ void coverage_band_poses(const query_dev &q, int first, int stride, int nposes, const double *__restrict__ proj,
                                                     const int *__restrict__ slots, double eps, int band_rows, int words_per_row,
                                                     unsigned long long *__restrict__ band_sums, unsigned int *s_bm, unsigned long long *s_sum,
@@ -1097,7 +1117,20 @@ __device__ __forceinline__ void coverage_band_poses(const query_dev &q, int firs
         rkx[k] = stage[e]; rky[k] = stage[cap + e]; rX[k] = stage[2 * cap + e]; rY[k] = stage[3 * cap + e]; rZ[k] = stage[4 * cap + e];
     }
     const double hw = (double)q.width / 2.0, hh = (double)q.height / 2.0;
+    // The pose matrices are wave-uniform and come through scalar loads issued one pose ahead (the
+    // index of the pose after that two ahead): a block would otherwise wait for two dependent
+    // memory round trips at the start of every pose.
+    auto slot_of = [&](int pose) { return __builtin_amdgcn_readfirstlane(pose < nposes ? (slots ? slots[pose] : pose) : 0); };
+    int slot_n = slot_of(first), slot_nn = slot_of(first + stride);
+    double Pn[12];
+    load_pose_uniform(proj, slot_n, Pn);
     for (int pose = first; pose < nposes; pose += stride) {
+        double P[12];
+#pragma unroll
+        for (int j = 0; j < 12; ++j) P[j] = Pn[j];
+        slot_n = slot_nn;
+        slot_nn = slot_of(pose + 2 * stride);
+        if (pose + stride < nposes) load_pose_uniform(proj, slot_n, Pn);
         __syncthreads();                                     // staging list / the previous pose's bitmap and sums are no longer read
         unsigned long long *out = band_sums + (size_t)pose * nbands + band;
         {
@@ -1107,7 +1140,6 @@ __device__ __forceinline__ void coverage_band_poses(const query_dev &q, int firs
         }
         if (tid == 0) s_any = 0;
         __syncthreads();
-        const double *P = proj + (size_t)(slots ? slots[pose] : pose) * 12;
 #pragma unroll
         for (int k = 0; k < COV_KEEP; ++k) {
             if (tid + k * (int)blockDim.x >= cnt) break;
@@ -1148,7 +1180,7 @@ __global__ __launch_bounds__(256) void k_coverage(query_dev q, int nposes, const
     __shared__ int s_any, s_cnt;
     const int n = nposes_dev ? *nposes_dev : nposes;
     if (!all_matches && n > (int)gridDim.x) {                // some block has several poses: share the scan of the correspondences
-        coverage_band_poses(q, blockIdx.x, gridDim.x, n, proj, slots, eps, band_rows, words_per_row, band_sums, s_bm, s_sum, s_any, s_cnt, blockIdx.y, gridDim.y);
+        coverage_band_poses<4>(q, blockIdx.x, gridDim.x, n, proj, slots, eps, band_rows, words_per_row, band_sums, s_bm, s_sum, s_any, s_cnt, blockIdx.y, gridDim.y);
         return;
     }
     for (int pose = blockIdx.x; pose < n; pose += gridDim.x) {

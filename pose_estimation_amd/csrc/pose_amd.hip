@@ -1110,7 +1110,9 @@ int pose_amd_ransac_run(pose_amd_ctx *ctx, const pose_amd_params *prm, pose_amd_
 
 
 // ---- many queries, segmented launches ------------------------------------------------------------
-// Coverage geometry of an image (the choices of coverage_dev for short lists of poses).
+// Coverage geometry of an image.
+// The multi-query launches have blocks enough from the queries alone, so their bands are thick (six
+// per image where the LDS allows): fewer painted rows above each band, fewer scans of the query.
 static bool coverage_geometry(int width, int height, int &band_rows, int &bands, int &wpr, int &separable, size_t &lds)
 {
     wpr = (width + 31) / 32;
@@ -1120,7 +1122,9 @@ static bool coverage_geometry(int width, int height, int &band_rows, int &bands,
     const int sep_rows = (lds_rows * 8) / 9 - 2 * half - 1;
     separable = sep_rows >= 8;
     const int max_rows = separable ? std::min(height, sep_rows) : std::max(1, std::min(height, (48 * 1024) / (wpr * 4)));
-    band_rows = std::max(1, std::min(max_rows, cdiv(height, 16)));
+    int nbands_want = 6;
+    if (const char *e = getenv("POSE_AMD_SEG_BANDS")) nbands_want = std::max(1, atoi(e));
+    band_rows = std::max(1, std::min(max_rows, cdiv(height, nbands_want)));
     bands = cdiv(height, band_rows);
     if (separable) {
         const int nh = band_rows + 2 * half - 1;
@@ -1384,7 +1388,7 @@ static int batch_run_segmented(pose_amd_batch *b, int sample_mode, uint64_t seed
     const int bands_max = b->bands_max;
     // blocks per (query, band) of the two coverage launches of a pass (records, candidates): every block
     // scans the query's correspondences once, so few blocks with several poses each
-    int cov_blocks[2] = {1, 4};
+    int cov_blocks[2] = {1, 2};
     if (const char *e = getenv("POSE_AMD_SEG_COV_BLOCKS")) {
         int a1 = 0, a2 = 0;
         if (sscanf(e, "%d,%d", &a1, &a2) == 2 && a1 > 0 && a2 > 0) { cov_blocks[0] = std::min(a1, 64); cov_blocks[1] = std::min(a2, 64); }
