@@ -453,7 +453,11 @@ def bench_dubrovnik(args):
                           "hypotheses_per_s": round(steps_total * args.steps / dt, 1),
                           "mean_steps_per_query": round(steps_total / max(len(res), 1), 1),
                           "queries_within_2_units_of_true_position": located}}
-        if world == 1:
+        if world == 1 and resident is not None and select == SELECT_COVERAGE:
+            out["roofline"] = roofline_shared_launches(resident, queries, res, sample_mode, select, args)
+            if not args.no_cpu_baseline:
+                out["cpu_baseline"] = cpu_baseline_batch(ctxs[0], queries, args, select, sample_mode)
+        elif world == 1:
             # Per-kernel times of this workload: a profiling pass outside the timed region, one
             # context with timing events, a sample of the queries one after the other.
             prof = Context(dev_index)
@@ -491,6 +495,61 @@ def bench_dubrovnik(args):
     if world > 1:
         dist.destroy_process_group()
     return 0
+
+
+LDS_PEAK_GBS = 256 * 128 * 2.4          # 256 CUs x 128 B per clock x 2.4 GHz
+
+
+def roofline_shared_launches(resident, queries, res, sample_mode, select, args):
+    """Roofline object of the batch path whose queries share their launches: one more run of the
+    resident list outside the timed region with a HIP event after every launch (on the library's
+    stream), summed by kernel.  The rounds are speculative, so the kernels process more RANSAC
+    steps than the results report; the algorithmic work is counted on the steps actually computed
+    (device counters), with the poses per step and correspondences per pose of the results."""
+    resident.set_timing(True)
+    raw = resident.run(sample_mode, seed=3000, budget=args.budget, select_mode=select, early_exit=args.early_exit, raw=True)
+    t = resident.last_timing()
+    resident.set_timing(False)
+    from pose_estimation_amd.api import result_dict
+    pairs = 0.0
+    pix = 0.0
+    stat = {True: [0, 0, 0.0, 0], False: [0, 0, 0.0, 0]}          # known focal: steps, poses, sum of n, queries
+    for (qi, q), rr in zip(queries, raw):
+        r = result_dict(rr)
+        st = stat[q["focal"] > 0]
+        st[0] += r["steps"]; st[1] += r["poses_scored"]; st[2] += len(q["kx"]); st[3] += 1
+        pix += float(q["width"]) * q["height"]
+    for known, computed in ((True, t["p3p_steps_computed"]), (False, t["p4pf_steps_computed"])):
+        st = stat[known]
+        if st[0]:
+            pairs += computed * (st[1] / st[0]) * (st[2] / st[3])
+    mean_pix = pix / max(len(queries), 1)
+    work = {"k_seg_score_screen": (t["score_ms"], pairs * SCORE_FLOP_PER_PAIR),
+            "k_seg_p4pf_elim": (t["elim_ms"], t["p4pf_steps_computed"] * ELIM_FLOP_PER_HYP),
+            "k_seg_p4pf_finish": (t["finish_ms"], t["p4pf_steps_computed"] * FINISH_FLOP_PER_HYP),
+            "k_seg_solve_p3p": (t["p3p_ms"], t["p3p_steps_computed"] * P3P_FLOP_PER_HYP)}
+    # coverage areas: no floating-point work; a pose's bitmap (one bit per pixel) is cleared and counted in LDS
+    cov_bytes = t["poses_painted"] * mean_pix / 8 * 2
+    times = dict((k, v[0]) for k, v in work.items())
+    times["k_seg_coverage"] = t["coverage_ms"]
+    dom = max(times, key=lambda k: times[k])
+    ms = {k: round(v, 3) for k, v in t.items() if k.endswith("_ms")}
+    if dom == "k_seg_coverage":
+        ach = cov_bytes / (t["coverage_ms"] * 1e-3) / 1e9
+        rl = {"kernel": dom, "bound": "lds", "achieved": round(ach, 1), "peak": round(LDS_PEAK_GBS, 1), "unit": "GB/s", "frac": round(ach / LDS_PEAK_GBS, 4),
+              "traffic": None, "algorithmic": "2 x width x height / 8 bytes of LDS per pose painted (clear the bitmap, count it)"}
+    else:
+        tf = work[dom][1] / (work[dom][0] * 1e-3) / 1e12 if work[dom][0] > 0 else 0.0
+        rl = {"kernel": dom, "bound": "valu_fp64", "achieved": round(tf, 3), "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
+              "frac": round(tf / FP64_VECTOR_PEAK_TFLOPS, 4), "traffic": None}
+    rl.update({"launches": t["launches"], "kernel_ms_per_step": ms,
+               "kernel_tflops": {k: round(f / (m * 1e-3) / 1e12, 3) for k, (m, f) in work.items() if m > 0},
+               "k_seg_coverage_lds_gbs": round(cov_bytes / (t["coverage_ms"] * 1e-3) / 1e9, 1) if t["coverage_ms"] > 0 else None,
+               "steps_computed": t["p3p_steps_computed"] + t["p4pf_steps_computed"], "poses_painted": t["poses_painted"],
+               "pairs_scored": round(pairs, 1),
+               "note": "HIP events after every launch of one run of the resident list (outside the timed region); kernel_ms_per_step is that run's "
+                       "sum per kernel; steps_computed counts the speculative rounds (64, 128, 256, ... steps for every query still running)"})
+    return rl
 
 
 def cpu_baseline_batch(ctx, queries, args, select, sample_mode):

@@ -187,6 +187,15 @@ int pose_amd_batch_size(const pose_amd_batch *batch);
 int pose_amd_batch_run(pose_amd_batch *batch, int sample_mode, uint64_t seed, uint32_t budget, const pose_amd_params *params,
                        pose_amd_result *results);
 void pose_amd_batch_destroy(pose_amd_batch *batch);
+/* Measurement: with timing on, a pose_amd_batch_run that shares its launches records a HIP event
+ * after every launch (on the stream the kernels run on) and pose_amd_batch_last_timing returns the
+ * sums by kind in ms: [0] sampling, [1] P3P, [2] P4Pf elimination, [3] P4Pf finish, [4] scoring,
+ * [5] coverage areas, [6] selection (lists of running queries, records, candidates, replay),
+ * [7] first to last event, [8] launches, [9] / [10] RANSAC steps computed for the P3P / P4Pf
+ * queries (rounds are speculative: more than the steps the results report), [11] poses whose
+ * coverage area was computed. */
+int pose_amd_batch_set_timing(pose_amd_batch *batch, int on);
+int pose_amd_batch_last_timing(const pose_amd_batch *batch, float ms[12]);
 
 /* ---- several GPUs of one node from one host process (the loop of benchmark.cpp:24 over devices) -- */
 /* Assignment of queries to `nparts` parts by descending cost (match count), each to the least

@@ -70,6 +70,8 @@ SIGNATURES = {
     "pose_amd_batch_size": (C.c_int, [C.c_void_p]),
     "pose_amd_batch_run": (C.c_int, [C.c_void_p, C.c_int, C.c_uint64, C.c_uint32, C.POINTER(Params), C.POINTER(Result)]),
     "pose_amd_batch_destroy": (None, [C.c_void_p]),
+    "pose_amd_batch_set_timing": (C.c_int, [C.c_void_p, C.c_int]),
+    "pose_amd_batch_last_timing": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
     "pose_amd_partition_queries": (C.c_int, [C.c_int, _ip, C.c_int, _ip]),
     "pose_amd_ransac_batch_multi": (C.c_int, [_ip, C.c_int, C.c_int, C.POINTER(QueryDesc), C.c_int, C.c_uint64, C.c_uint32, C.POINTER(Params),
                                               C.POINTER(Result)]),

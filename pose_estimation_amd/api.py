@@ -56,6 +56,16 @@ class ResidentBatch:
         self._ctx._chk(self._ctx._lib.pose_amd_batch_run(self._b, int(sample_mode), int(seed), int(budget), C.byref(prm), res), "batch_run")
         return res if raw else [result_dict(r) for r in res[:self.nq]]
 
+    def set_timing(self, on=True):
+        self._ctx._chk(self._ctx._lib.pose_amd_batch_set_timing(self._b, int(bool(on))), "batch_set_timing")
+
+    def last_timing(self):
+        """HIP-event kernel times (ms, summed by kind) of the last run with timing on."""
+        ms = (C.c_float * 12)()
+        self._ctx._chk(self._ctx._lib.pose_amd_batch_last_timing(self._b, ms), "batch_last_timing")
+        return dict(sample_ms=ms[0], p3p_ms=ms[1], elim_ms=ms[2], finish_ms=ms[3], score_ms=ms[4], coverage_ms=ms[5], select_ms=ms[6],
+                    total_ms=ms[7], launches=int(ms[8]), p3p_steps_computed=int(ms[9]), p4pf_steps_computed=int(ms[10]), poses_painted=int(ms[11]))
+
     def close(self):
         if self._b:
             self._ctx._lib.pose_amd_batch_destroy(self._b)

@@ -51,7 +51,8 @@ __device__ __forceinline__ const seg_query &seg_of(const seg_launch &L, int p) {
 // One block; the list keeps the order of cand.
 __global__ __launch_bounds__(COVSEL_THREADS) void k_seg_compact(const seg_query *__restrict__ qt, const int *__restrict__ cand, int ncand,
                                                                  const unsigned long long *__restrict__ state, int early_exit,
-                                                                 int *__restrict__ active, int *__restrict__ n_active)
+                                                                 int *__restrict__ active, int *__restrict__ n_active, int steps,
+                                                                 unsigned long long *__restrict__ steps_issued)
 {
     __shared__ int s_tmp[COVSEL_THREADS / 64];
     int n = 0;
@@ -68,7 +69,10 @@ __global__ __launch_bounds__(COVSEL_THREADS) void k_seg_compact(const seg_query 
         if (on) active[off] = qi;
         n += total;
     }
-    if (threadIdx.x == 0) *n_active = n;
+    if (threadIdx.x == 0) {
+        *n_active = n;
+        *steps_issued += (unsigned long long)n * (unsigned)steps;      // RANSAC steps computed for this solver so far (measurement only)
+    }
 }
 
 __global__ void k_seg_sample_basic(seg_launch L, uint64_t seed, uint32_t *__restrict__ samples)
@@ -233,7 +237,8 @@ __global__ __launch_bounds__(COVSEL_THREADS) void k_seg_cov_candidates(seg_launc
 // | its solution) or 0, unused.  The state words of a query keep the kept pose's record and matrix.
 __global__ __launch_bounds__(COVSEL_THREADS) void k_seg_cov_final(seg_launch L, seg_cov C, int early_exit, const int *__restrict__ counts,
                                                                    const int *__restrict__ nsol, const double *__restrict__ pose,
-                                                                   const double *__restrict__ proj, unsigned long long *__restrict__ totals)
+                                                                   const double *__restrict__ proj, unsigned long long *__restrict__ totals,
+                                                                   unsigned long long *__restrict__ poses_painted)
 {
     __shared__ cov_final_lds lds;
     const int a = blockIdx.x;
@@ -241,6 +246,7 @@ __global__ __launch_bounds__(COVSEL_THREADS) void k_seg_cov_final(seg_launch L, 
     const seg_query &sq = seg_of(L, a);
     const size_t base = (size_t)a * L.S, sbase = base * sq.maxsol;
     unsigned long long *state = C.state + (size_t)seg_index(L, a) * 33;
+    if (threadIdx.x == 0) atomicAdd(poses_painted, (unsigned long long)(min(C.n[4 * a], C.cap1) + min(C.n[4 * a + 1], C.cap2)));   // measurement only
     if (C.n[4 * a] > C.cap1 || C.n[4 * a + 1] > C.cap2) {   // block-uniform
         if (threadIdx.x == 0) state[7] = 1ull;
         return;

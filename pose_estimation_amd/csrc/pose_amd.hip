@@ -1150,6 +1150,10 @@ struct pose_amd_batch {
     pin_buf h_qtab, h_lists, h_out;
     int bands_max = 1, bm_max = 0;
     size_t lds_cov = 0;
+    // measurement (pose_amd_batch_set_timing): events around every launch of a run, summed by kind
+    bool timing = false;
+    std::vector<hipEvent_t> events;
+    float last_ms[12] = {0};
 };
 
 static void batch_free(pose_amd_batch *b)
@@ -1159,6 +1163,7 @@ static void batch_free(pose_amd_batch *b)
     for (dev_buf *d : bufs) if (d->p) { (void)hipFree(d->p); d->p = nullptr; d->cap = 0; }
     pin_buf *pins[] = {&b->hpack, &b->h_qtab, &b->h_lists, &b->h_out};
     for (pin_buf *d : pins) if (d->p) { (void)hipHostFree(d->p); d->p = nullptr; d->cap = 0; }
+    for (hipEvent_t e : b->events) (void)hipEventDestroy(e);
     delete b;
 }
 
@@ -1220,7 +1225,7 @@ static int batch_fill(pose_amd_ctx *ctx, pose_amd_batch *b, int nq, const pose_a
     if ((rc = ensure(ctx, b->qpack, total)) || (rc = ensure_pinned(ctx, b->hpack, total)) || (rc = ensure(ctx, b->qtab, (size_t)nq * sizeof(seg_query))) ||
         (rc = ensure_pinned(ctx, b->h_qtab, (size_t)nq * sizeof(seg_query))) || (rc = ensure(ctx, b->lists, (size_t)nq * 16 + 64)) ||
         (rc = ensure_pinned(ctx, b->h_lists, (size_t)nq * 8)) || (rc = ensure(ctx, b->state, (size_t)nq * 33 * 8)) ||
-        (rc = ensure(ctx, b->totals, (size_t)nq * 32)) || (rc = ensure_pinned(ctx, b->h_out, (size_t)nq * (33 + 4) * 8)))
+        (rc = ensure(ctx, b->totals, (size_t)nq * 32 + 32)) || (rc = ensure_pinned(ctx, b->h_out, (size_t)nq * (33 + 4) * 8 + 32)))
         return rc;
     b->qt.assign((size_t)nq, seg_query());
     b->host_q.assign(queries, queries + nq);
@@ -1365,7 +1370,19 @@ static int batch_run_segmented(pose_amd_batch *b, int sample_mode, uint64_t seed
     HIPCHK(ctx, hipMemcpyAsync(b->qtab.p, qt, (size_t)nq * sizeof(seg_query), hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(dl, hl, (size_t)nlive * 4, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipMemsetAsync(b->state.p, 0, (size_t)nq * 33 * 8, ctx->stream));
-    HIPCHK(ctx, hipMemsetAsync(b->totals.p, 0, (size_t)nq * 32, ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(b->totals.p, 0, (size_t)nq * 32 + 32, ctx->stream));
+    unsigned long long *issued_dev = (unsigned long long *)b->totals.p + (size_t)nq * 4;      // [0], [1]: steps computed per solver, [2]: poses painted
+    // measurement: kinds 0 sampling, 1 P3P, 2 elimination, 3 finish, 4 scoring, 5 coverage areas, 6 selection (lists, replay)
+    size_t nev = 0;
+    std::vector<int> ev_kind;
+    auto mark = [&](int kind) -> int {
+        if (!b->timing) return POSE_AMD_OK;
+        if (nev == b->events.size()) { hipEvent_t e; HIPCHK(ctx, hipEventCreate(&e)); b->events.push_back(e); }
+        HIPCHK(ctx, hipEventRecord(b->events[nev++], ctx->stream));
+        ev_kind.push_back(kind);
+        return POSE_AMD_OK;
+    };
+    if ((rc = mark(-1))) return rc;
 
     // room per query and round for count records / candidates of the selection; a query that needs more
     // takes the per-query path (POSE_AMD_SEG_CAPS="records,candidates" shrinks them, for tests of that route)
@@ -1402,7 +1419,8 @@ static int batch_run_segmented(pose_amd_batch *b, int sample_mode, uint64_t seed
             if (nsolver[solver] == 0) continue;
             const int maxsol = solver ? P4PF_MAXSOL : P3P_MAXSOL;
             hipLaunchKernelGGL(k_seg_compact, dim3(1), dim3(COVSEL_THREADS), 0, ctx->stream, (const seg_query *)b->qtab.p, (const int *)cand_dev[solver],
-                               nsolver[solver], (const unsigned long long *)b->state.p, early ? 1 : 0, active_dev[solver], nact_dev[solver]);
+                               nsolver[solver], (const unsigned long long *)b->state.p, early ? 1 : 0, active_dev[solver], nact_dev[solver], (int)valid, issued_dev + solver);
+            if ((rc = mark(6))) return rc;
             const size_t per_hyp = (size_t)maxsol * (96 + 104 + 128 + 4) + 16 + 4 + 4 + (solver ? P4PF_TAIL * 8 + 4 : 0);
             // after the first round only queries that did not end in it are left: at most all of them
             const int per_pass = (int)std::max<size_t>(1, std::min<size_t>((size_t)nsolver[solver], std::min<size_t>(32768, pass_bytes / ((size_t)S * per_hyp))));
@@ -1428,34 +1446,44 @@ static int batch_run_segmented(pose_amd_batch *b, int sample_mode, uint64_t seed
                                        (int *)ctx->sg_sstatus.p, std::max(b->bm_max, 1));
                 else
                     hipLaunchKernelGGL(k_seg_sample_basic, dim3(cdiv(valid, 256), (unsigned)na), dim3(256), 0, ctx->stream, L, seed, samples);
+                if ((rc = mark(0))) return rc;
                 if (solver) {
                     // batch size as in launch_p4pf: 32 systems per block unless that leaves wave slots of the chip empty
                     const int wslots = (ctx->cus ? ctx->cus : 256) * 8;
                     const int batch = std::max(4, std::min(4 * cdiv(cdiv((long long)na * valid, wslots), 4), ELIM_BATCH));
                     hipLaunchKernelGGL(k_seg_p4pf_elim, dim3(cdiv(valid, batch), (unsigned)na), dim3(64), 0, ctx->stream, L, (const uint32_t *)samples,
                                        (double *)ctx->sg_arows.p, (int *)ctx->sg_pstatus.p, batch);
+                    if ((rc = mark(2))) return rc;
                     hipLaunchKernelGGL(k_seg_p4pf_finish, dim3(cdiv(valid, 64), (unsigned)na), dim3(64), 0, ctx->stream, L, (const uint32_t *)samples,
                                        (const double *)ctx->sg_arows.p, (const int *)ctx->sg_pstatus.p, proj, pose, nsol, projf, prm->eps);
+                    if ((rc = mark(3))) return rc;
                 } else {
                     hipLaunchKernelGGL(k_seg_solve_p3p, dim3(cdiv(valid, 64), (unsigned)na), dim3(64), 0, ctx->stream, L, (const uint32_t *)samples, proj, pose, nsol, projf,
                                        prm->eps);
+                    if ((rc = mark(1))) return rc;
                 }
                 // slots per block as in launch_score: as many as possible while the launch keeps about four blocks per compute unit
                 int spb = SCORE_SPB;
                 while (spb > 8 && (long long)na * cdiv((long long)valid * maxsol, spb) < (ctx->cus ? ctx->cus : 256) * 4) spb >>= 1;
                 hipLaunchKernelGGL(k_seg_score_screen, dim3(cdiv((long long)valid * maxsol, spb), (unsigned)na), dim3(SCORE_THREADS), 0, ctx->stream, L, maxsol,
                                    (const double *)proj, (const float *)projf, (const int *)nsol, prm->eps, counts, spb);
+                if ((rc = mark(4))) return rc;
                 seg_cov C{(unsigned long long *)b->state.p, (int *)ctx->sg_n.p, (int *)ctx->sg_list1.p, (long long *)ctx->sg_area1.p,
                           (unsigned long long *)ctx->sg_bands1.p, cap1, (int *)ctx->sg_list2.p, (unsigned long long *)ctx->sg_bands2.p, cap2,
                           (int *)ctx->sg_mslot.p, (long long *)ctx->sg_marea.p, (unsigned char *)ctx->sg_mkeep.p, bands_max};
                 hipLaunchKernelGGL(k_seg_cov_records, dim3((unsigned)na), dim3(COVSEL_THREADS), 0, ctx->stream, L, C, (const int *)counts, (const int *)nsol);
+                if ((rc = mark(6))) return rc;
                 hipLaunchKernelGGL(k_seg_coverage, dim3(cov_blocks[0], bands_max, (unsigned)na), dim3(256), b->lds_cov, ctx->stream, L, C, 0, (const double *)proj, prm->eps);
+                if ((rc = mark(5))) return rc;
                 hipLaunchKernelGGL(k_seg_cov_candidates, dim3((unsigned)na), dim3(COVSEL_THREADS), 0, ctx->stream, L, C, early ? 1 : 0, (const int *)counts,
                                    (const int *)nsol);
+                if ((rc = mark(6))) return rc;
                 hipLaunchKernelGGL(k_seg_coverage, dim3(cov_blocks[1], bands_max, (unsigned)na), dim3(256), b->lds_cov, ctx->stream, L, C, 1, (const double *)proj, prm->eps);
+                if ((rc = mark(5))) return rc;
                 hipLaunchKernelGGL(k_seg_cov_final, dim3((unsigned)na), dim3(COVSEL_THREADS), 0, ctx->stream, L, C, early ? 1 : 0, (const int *)counts,
-                                   (const int *)nsol, (const double *)pose, (const double *)proj, (unsigned long long *)b->totals.p);
+                                   (const int *)nsol, (const double *)pose, (const double *)proj, (unsigned long long *)b->totals.p, issued_dev + 2);
                 HIPCHK(ctx, hipGetLastError());
+                if ((rc = mark(6))) return rc;
                 if (stats) {                                   // list lengths of the pass (this waits for the device)
                     std::vector<int> nn(na * 4, 0);
                     int nact = 0;
@@ -1477,10 +1505,23 @@ static int batch_run_segmented(pose_amd_batch *b, int sample_mode, uint64_t seed
     lap("issued");
     // ---- outcome -------------------------------------------------------------------------------------
     unsigned long long *out = (unsigned long long *)b->h_out.p;
-    if ((rc = download(ctx, out, b->state.p, (size_t)nq * 33 * 8)) || (rc = download(ctx, out + (size_t)nq * 33, b->totals.p, (size_t)nq * 32)) ||
+    if ((rc = download(ctx, out, b->state.p, (size_t)nq * 33 * 8)) || (rc = download(ctx, out + (size_t)nq * 33, b->totals.p, (size_t)nq * 32 + 32)) ||
         (rc = pose_amd_synchronize(ctx)))
         return rc;
     lap("done");
+    memset(b->last_ms, 0, sizeof b->last_ms);
+    if (b->timing) {
+        for (size_t i = 1; i < nev; ++i) {
+            float ms = 0.f;
+            (void)hipEventElapsedTime(&ms, b->events[i - 1], b->events[i]);
+            b->last_ms[ev_kind[i]] += ms;
+        }
+        (void)hipEventElapsedTime(&b->last_ms[7], b->events[0], b->events[nev - 1]);
+        b->last_ms[8] = (float)(nev - 1);
+        b->last_ms[9] = (float)out[(size_t)nq * 37];          // P3P steps computed
+        b->last_ms[10] = (float)out[(size_t)nq * 37 + 1];     // P4Pf steps computed
+        b->last_ms[11] = (float)out[(size_t)nq * 37 + 2];     // poses whose coverage area was computed
+    }
     for (int i = 0; i < nq; ++i) {
         if (!live[(size_t)i]) continue;
         const unsigned long long *w = out + (size_t)i * 33, *t = out + (size_t)nq * 33 + (size_t)i * 4;
@@ -1631,6 +1672,20 @@ int pose_amd_batch_create(pose_amd_ctx *ctx, int nq, const pose_amd_query *queri
 }
 
 int pose_amd_batch_size(const pose_amd_batch *b) { return b ? b->nq : 0; }
+
+int pose_amd_batch_set_timing(pose_amd_batch *b, int on)
+{
+    if (!b) return POSE_AMD_EINVAL;
+    b->timing = on != 0;
+    return POSE_AMD_OK;
+}
+
+int pose_amd_batch_last_timing(const pose_amd_batch *b, float ms[12])
+{
+    if (!b || !ms) return POSE_AMD_EINVAL;
+    memcpy(ms, b->last_ms, sizeof b->last_ms);
+    return POSE_AMD_OK;
+}
 
 int pose_amd_batch_run(pose_amd_batch *b, int sample_mode, uint64_t seed, uint32_t budget, const pose_amd_params *prm, pose_amd_result *results)
 {
