@@ -28,6 +28,7 @@ struct seg_query {
     int band_rows, bands, wpr;   // coverage geometry of the query's image
     int separable;               // the row-union coverage kernel fits this image
     int bm_words;                // advanced sampler: words of the camera bitmap, 0 = merge lists
+    int cv_rows;                 // output rows per pass of k_seg_cover_pose, 0: the query's areas come from k_seg_coverage
 };
 
 // what a launch needs to find its query and its segment
@@ -180,7 +181,7 @@ __global__ __launch_bounds__(256) void k_seg_coverage(seg_launch L, seg_cov C, i
     const int a = blockIdx.z;
     if (!seg_live(L, a)) return;
     const seg_query &sq = seg_of(L, a);
-    if ((int)blockIdx.y >= sq.bands) return;
+    if ((int)blockIdx.y >= sq.bands || sq.cv_rows) return;
     const int cap = which ? C.cap2 : C.cap1;
     const int n = min(C.n[4 * a + which], cap);
     const int *list = which ? C.list2 + (size_t)a * C.cap2 : C.list1 + (size_t)a * C.cap1;
@@ -193,6 +194,181 @@ __global__ __launch_bounds__(256) void k_seg_coverage(seg_launch L, seg_cov C, i
     for (int pose = blockIdx.x; pose < n; pose += gridDim.x) {
         coverage_band_direct(sq.q, pose, pq, list, eps, 0, sq.band_rows, sq.wpr, sums, s_bm, s_sum, blockIdx.y, sq.bands);
         __syncthreads();
+    }
+}
+
+// Coverage areas, one block per pose (the common case of the multi-query launches: queries of up to
+// 256 * CVP_KM correspondences on images whose bitmap rows are short enough).  The block first
+// decides the pose's inliers (the float64 test of the scoring kernels; every thread keeps the bits
+// of its CVP_KM correspondences, whose integer keypoint positions it holds packed in registers for
+// all poses of the block), then walks over the image in passes of cv_rows output rows: clear the
+// pass's rows in LDS, paint every inlier's column interval into the row of its own y, form the
+// unions of aligned groups of eight rows, form every output row as the union of the 2h painted
+// rows above it and count (the scheme of coverage_band).  Differences that make it cheaper per
+// pose: 64-bit bitmap words; rows padded with never-painted ones so that no read needs a clamp or
+// a test; the (group, column) items of a thread are stepped, not divided out; the correspondences
+// are tested once per pose, not once per band; the block adds up its passes itself.  Short lists
+// (count records, candidates under early exit) are latency, not throughput: gridDim.y blocks then
+// share the passes of a pose and write partial sums into the pose's band sums.
+// Dynamic LDS: (nhp + nhp / 8) * W * 8 bytes, nhp = roundup8(cv_rows + 2h - 1) + 8, W = ceil(width / 64).
+#ifndef CVP_T
+#define CVP_T 512
+#endif
+constexpr int CVP_THREADS = CVP_T;       // threads per block
+constexpr int CVP_KM = 6144 / CVP_THREADS;   // correspondences per thread
+constexpr int CVP_BIAS = 16384;          // keypoint coordinates are stored as 16-bit values with this bias
+
+__global__ __launch_bounds__(CVP_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_seg_cover_pose(seg_launch L, seg_cov C, int which, const double *__restrict__ proj, double eps)
+{
+    extern __shared__ unsigned long long s_rows[];
+    __shared__ unsigned long long s_red[CVP_THREADS / 64];
+    __shared__ int s_any;
+    const int a = blockIdx.z;
+    if (!seg_live(L, a)) return;
+    const seg_query &sq = seg_of(L, a);
+    if (!sq.cv_rows) return;
+    const int cap = which ? C.cap2 : C.cap1;
+    const int n = min(C.n[4 * a + which], cap);
+    // blockIdx.y: the block's share of the passes (pass y, y + ny, ...); its sum goes into band y of the pose's sums
+    const int ny = min((int)gridDim.y, sq.bands);
+    if ((int)blockIdx.x >= n || (int)blockIdx.y >= ny) return;
+    const int *list = which ? C.list2 + (size_t)a * C.cap2 : C.list1 + (size_t)a * C.cap1;
+    unsigned long long *sums = which ? C.bands2 + (size_t)a * C.cap2 * C.bands_max : C.bands1 + (size_t)a * C.cap1 * C.bands_max;
+    const double *pq = proj + (size_t)a * L.S * sq.maxsol * 12;
+    const query_dev &q = sq.q;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int W = (q.width + 63) >> 6;
+    const int h = (int)ceilf((float)q.width / 20.0f) / 2;        // 2h >= 8: the host routes smaller boxes to k_seg_coverage
+    const int RB = sq.cv_rows;
+    const int nhp = ((RB + 2 * h - 1 + 7) & ~7) + 8, ngp = nhp >> 3;
+    unsigned long long *Hm = s_rows, *G = s_rows + nhp * W;
+    const int m = (2 * h) >> 3, e = (2 * h) & 7;
+    const double hw = (double)q.width / 2.0, hh = (double)q.height / 2.0;
+    // the thread's correspondences tid + 256 k: biased integer keypoint (x | y << 16), ~0 when the box is empty
+    unsigned rxy[CVP_KM];
+#pragma unroll
+    for (int k = 0; k < CVP_KM; ++k) {
+        const int i = tid + k * CVP_THREADS;
+        unsigned v = 0xFFFFFFFFu;
+        if (i < q.n) {
+            const int x = (int)rintf(q.kx[i]), y = (int)rintf(q.ky[i]);
+            const int sx = max(0, min(x - h, q.width - 1)), sy = max(0, min(y - h, q.height - 1));
+            const int ex = max(0, min(x + h, q.width - 1)), ey = max(0, min(y + h, q.height - 1));
+            if (sy < ey && sx < ex) v = (unsigned)(x + CVP_BIAS) | ((unsigned)(y + CVP_BIAS) << 16);   // then -h < x < width + h, likewise y
+        }
+        rxy[k] = v;
+    }
+    // (group, column) of the thread's first item and the step to its next one
+    const int g_first = tid / W, c_first = tid - g_first * W, g_step = CVP_THREADS / W, c_step = CVP_THREADS - g_step * W;
+    const int total_words = (nhp + ngp) * W;
+
+    for (int pose = blockIdx.x; pose < n; pose += gridDim.x) {
+        double P[12];
+        load_pose_uniform(pq, __builtin_amdgcn_readfirstlane(list[pose]), P);
+        // ---- the pose's inliers among the thread's correspondences --------------------------------
+        unsigned inl = 0;
+#pragma unroll
+        for (int k = 0; k < CVP_KM; ++k) {
+            if (k * CVP_THREADS >= q.n) break;                       // block-uniform
+            const int i = min(tid + k * CVP_THREADS, q.n - 1);       // loads without a branch in front of them
+            const float kxf = q.kx[i], kyf = q.ky[i];
+            const double X = q.X[i], Y = q.Y[i], Z = q.Z[i];
+            const double u = -((double)kxf - hw), v = -((double)kyf - hh);
+            const double px = fma(P[0], X, fma(P[1], Y, fma(P[2], Z, P[3])));
+            const double py = fma(P[4], X, fma(P[5], Y, fma(P[6], Z, P[7])));
+            const double pz = fma(P[8], X, fma(P[9], Y, fma(P[10], Z, P[11])));
+            const double rx = fma(u, pz, -px), ry = fma(v, pz, -py);
+            const double te = eps * pz;
+            if (rxy[k] != 0xFFFFFFFFu && fma(ry, ry, rx * rx) < te * te) inl |= 1u << k;     // rxy is ~0 beyond n as well
+        }
+        unsigned long long area = 0;
+        for (int row0 = (int)blockIdx.y * RB; row0 < q.height; row0 += ny * RB) {
+            const int row1 = min(q.height, row0 + RB);
+            const int nh = (row1 - row0) + 2 * h - 1, ng = (nh + 7) >> 3;
+            const int y_base = row0 - h + 1;
+            __syncthreads();                                 // the previous pass (or pose) is done with the rows
+            {
+                uint4 *v = reinterpret_cast<uint4 *>(s_rows);
+                for (int i = tid; i < total_words / 2; i += CVP_THREADS) v[i] = make_uint4(0u, 0u, 0u, 0u);
+                if (tid == 0 && (total_words & 1)) s_rows[total_words - 1] = 0ull;
+            }
+            if (tid == 0) s_any = 0;
+            __syncthreads();
+            bool any = false;
+#pragma unroll
+            for (int k = 0; k < CVP_KM; ++k) {
+                if (!((inl >> k) & 1u)) continue;
+                const int x = (int)(rxy[k] & 0xFFFFu) - CVP_BIAS, y = (int)(rxy[k] >> 16) - CVP_BIAS;
+                const int yy = y - y_base;
+                if ((unsigned)yy >= (unsigned)nh) continue;      // the box does not touch this pass's rows
+                const int sx = max(0, min(x - h, q.width - 1)), ex = max(0, min(x + h, q.width - 1));
+                const int w0 = sx >> 6, w1 = (ex - 1) >> 6;
+                for (int w = w0; w <= w1; ++w) {
+                    unsigned long long bits = ~0ull;
+                    if (w == w0) bits &= ~0ull << (sx & 63);
+                    if (w == w1) bits &= ~0ull >> (63 - ((ex - 1) & 63));
+                    atomicOr(&Hm[yy * W + w], bits);
+                }
+                any = true;
+            }
+            if (any) s_any = 1;
+            __syncthreads();
+            if (!s_any) continue;                            // no inlier near these rows (block-uniform)
+            for (int g = g_first, c = c_first; g < ng; ) {
+                const unsigned long long *base = Hm + (8 * g) * W + c;
+                unsigned long long r[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) r[j] = base[j * W];
+                G[g * W + c] = ((r[0] | r[1]) | (r[2] | r[3])) | ((r[4] | r[5]) | (r[6] | r[7]));
+                g += g_step; c += c_step;
+                if (c >= W) { c -= W; ++g; }
+            }
+            __syncthreads();
+            // output row row0 + rr = union of the painted rows rr .. rr + 2h - 1 (2h = 8m + e); the
+            // last image row is never covered
+            const int rows_out = min(row1, q.height - 1) - row0;
+            const int nk = (rows_out + 7) >> 3;
+            for (int k = g_first, c = c_first; k < nk; ) {
+                const unsigned long long *hk = Hm + (8 * k) * W + c, *tp = Hm + (8 * (k + m)) * W + c, *gp = G + (k + 1) * W + c;
+                unsigned long long hv[8], tv[7], uv[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) hv[j] = hk[j * W];
+#pragma unroll
+                for (int i = 0; i < 7; ++i) tv[i] = tp[i * W];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) uv[j] = tp[(e + j) * W];
+                unsigned long long common = 0;
+                for (int g = 0; g < m - 1; g += 4) {
+                    unsigned long long gv[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) gv[j] = gp[min(g + j, m - 2) * W];   // a repeated group changes nothing
+                    common |= (gv[0] | gv[1]) | (gv[2] | gv[3]);
+                }
+                unsigned long long suf[8], acc = 0;
+#pragma unroll
+                for (int j = 7; j >= 0; --j) { acc |= hv[j]; suf[j] = acc; }
+                unsigned long long pre = 0;
+#pragma unroll
+                for (int i = 0; i < 7; ++i) if (i < e) pre |= tv[i];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    if (8 * k + j < rows_out) area += __popcll(suf[j] | common | pre);
+                    pre |= uv[j];
+                }
+                k += g_step; c += c_step;
+                if (c >= W) { c -= W; ++k; }
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) area += __shfl_xor(area, o);
+        __syncthreads();                                     // s_red of the previous pose has been read
+        if (lane == 0) s_red[tid >> 6] = area;
+        __syncthreads();
+        unsigned long long whole = 0;
+#pragma unroll
+        for (int w = 0; w < CVP_THREADS / 64; ++w) whole += s_red[w];
+        if (tid == 0) sums[(size_t)pose * sq.bands + blockIdx.y] = whole;
+        if (blockIdx.y == 0) for (int b = ny + tid; b < sq.bands; b += CVP_THREADS) sums[(size_t)pose * sq.bands + b] = 0ull;
     }
 }
 

@@ -1149,7 +1149,8 @@ struct pose_amd_batch {
     dev_buf qpack, qtab, lists, state, totals;
     pin_buf h_qtab, h_lists, h_out;
     int bands_max = 1, bm_max = 0;
-    size_t lds_cov = 0;
+    size_t lds_cov = 0, lds_pose = 0;         // dynamic LDS of k_seg_coverage / k_seg_cover_pose (0: no query uses the latter)
+    bool any_band_cover = false;              // some query's areas come from k_seg_coverage
     // measurement (pose_amd_batch_set_timing): events around every launch of a run, summed by kind
     bool timing = false;
     std::vector<hipEvent_t> events;
@@ -1269,6 +1270,15 @@ static int batch_fill(pose_amd_ctx *ctx, pose_amd_batch *b, int nq, const pose_a
                 sq.box = (long long)(2 * (cover / 2)) * (2 * (cover / 2));
                 size_t lds = 0;
                 if (!coverage_geometry(q.width, q.height, sq.band_rows, sq.bands, sq.wpr, sq.separable, lds)) { bad_geometry = 1; continue; }
+                {   // one block per pose where the query fits it: rows per pass from 60 KB of LDS
+                    const int W = (q.width + 63) / 64, h2 = 2 * ((int)std::ceil((float)q.width / 20.0f) / 2);
+                    const int rows_total = (60 * 1024) / (8 * W);
+                    const int nhp = (rows_total * 8 / 9) & ~7;
+                    int rb = (nhp - 8 - (h2 - 1)) & ~7;
+                    rb = std::min(rb, (q.height + 7) & ~7);
+                    static const bool off = getenv("POSE_AMD_SEG_COVER") && strcmp(getenv("POSE_AMD_SEG_COVER"), "bands") == 0;
+                    sq.cv_rows = (!off && q.n <= CVP_THREADS * CVP_KM && h2 >= 8 && rb >= 8 && q.width <= 16384 && q.height <= 16384) ? rb : 0;
+                }
                 if (all_cams) {
                     memcpy(hp + e.cam_off_at, q.cam_off, ((size_t)q.n + 1) * 4);
                     memcpy(hp + e.cam_ids_at, q.cam_ids, (size_t)q.cam_off[q.n] * 4);
@@ -1287,8 +1297,16 @@ static int batch_fill(pose_amd_ctx *ctx, pose_amd_batch *b, int nq, const pose_a
         for (std::thread &t : pool) t.join();
     }
     if (bad_geometry.load()) return fail(ctx, POSE_AMD_EINVAL, "coverage: image wider than 393216 px");
-    b->lds_cov = 0; b->bands_max = 1; b->bm_max = 0;
+    b->lds_cov = 0; b->bands_max = 1; b->bm_max = 0; b->lds_pose = 0; b->any_band_cover = false;
     for (int i = 0; i < nq; ++i) {
+        const seg_query &sq = b->qt[(size_t)i];
+        if (sq.cv_rows) {
+            const int W = (sq.q.width + 63) / 64, h2 = 2 * ((int)std::ceil((float)sq.q.width / 20.0f) / 2);
+            const int nhp = ((sq.cv_rows + h2 - 1 + 7) & ~7) + 8;
+            b->lds_pose = std::max(b->lds_pose, (size_t)(nhp + nhp / 8) * W * 8);
+        } else {
+            b->any_band_cover = true;
+        }
         size_t lds = 0;
         int br, bn, wp, sep;
         coverage_geometry(queries[i].width, queries[i].height, br, bn, wp, sep, lds);
@@ -1405,6 +1423,14 @@ static int batch_run_segmented(pose_amd_batch *b, int sample_mode, uint64_t seed
     const int bands_max = b->bands_max;
     // blocks per (query, band) of the two coverage launches of a pass (records, candidates): every block
     // scans the query's correspondences once, so few blocks with several poses each
+    // k_seg_cover_pose: blocks per query that share the list's poses round-robin (records, candidates) and
+    // blocks that share the passes of a pose: short lists are a chain of latencies, long ones want throughput
+    int pose_blocks[4] = {4, 16, 1, 1};          // (sharing the passes measured slower for both benchmark batches)
+    if (const char *e = getenv("POSE_AMD_SEG_POSE_BLOCKS")) {
+        int v[4] = {0, 0, 0, 0};
+        if (sscanf(e, "%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3]) == 4 && v[0] > 0 && v[1] > 0 && v[2] > 0 && v[3] > 0)
+            for (int i = 0; i < 4; ++i) pose_blocks[i] = std::min(v[i], 1024);
+    }
     int cov_blocks[2] = {1, 2};
     if (const char *e = getenv("POSE_AMD_SEG_COV_BLOCKS")) {
         int a1 = 0, a2 = 0;
@@ -1473,12 +1499,18 @@ static int batch_run_segmented(pose_amd_batch *b, int sample_mode, uint64_t seed
                           (int *)ctx->sg_mslot.p, (long long *)ctx->sg_marea.p, (unsigned char *)ctx->sg_mkeep.p, bands_max};
                 hipLaunchKernelGGL(k_seg_cov_records, dim3((unsigned)na), dim3(COVSEL_THREADS), 0, ctx->stream, L, C, (const int *)counts, (const int *)nsol);
                 if ((rc = mark(6))) return rc;
-                hipLaunchKernelGGL(k_seg_coverage, dim3(cov_blocks[0], bands_max, (unsigned)na), dim3(256), b->lds_cov, ctx->stream, L, C, 0, (const double *)proj, prm->eps);
+                if (b->any_band_cover)
+                    hipLaunchKernelGGL(k_seg_coverage, dim3(cov_blocks[0], bands_max, (unsigned)na), dim3(256), b->lds_cov, ctx->stream, L, C, 0, (const double *)proj, prm->eps);
+                if (b->lds_pose)
+                    hipLaunchKernelGGL(k_seg_cover_pose, dim3(pose_blocks[0], pose_blocks[2], (unsigned)na), dim3(CVP_THREADS), b->lds_pose, ctx->stream, L, C, 0, (const double *)proj, prm->eps);
                 if ((rc = mark(5))) return rc;
                 hipLaunchKernelGGL(k_seg_cov_candidates, dim3((unsigned)na), dim3(COVSEL_THREADS), 0, ctx->stream, L, C, early ? 1 : 0, (const int *)counts,
                                    (const int *)nsol);
                 if ((rc = mark(6))) return rc;
-                hipLaunchKernelGGL(k_seg_coverage, dim3(cov_blocks[1], bands_max, (unsigned)na), dim3(256), b->lds_cov, ctx->stream, L, C, 1, (const double *)proj, prm->eps);
+                if (b->any_band_cover)
+                    hipLaunchKernelGGL(k_seg_coverage, dim3(cov_blocks[1], bands_max, (unsigned)na), dim3(256), b->lds_cov, ctx->stream, L, C, 1, (const double *)proj, prm->eps);
+                if (b->lds_pose)
+                    hipLaunchKernelGGL(k_seg_cover_pose, dim3(pose_blocks[1], pose_blocks[3], (unsigned)na), dim3(CVP_THREADS), b->lds_pose, ctx->stream, L, C, 1, (const double *)proj, prm->eps);
                 if ((rc = mark(5))) return rc;
                 hipLaunchKernelGGL(k_seg_cov_final, dim3((unsigned)na), dim3(COVSEL_THREADS), 0, ctx->stream, L, C, early ? 1 : 0, (const int *)counts,
                                    (const int *)nsol, (const double *)pose, (const double *)proj, (unsigned long long *)b->totals.p, issued_dev + 2);
