@@ -447,7 +447,7 @@ def bench_dubrovnik(args):
                           "parallelism": "queries partitioned over %d GPU(s), %s" % (
                               world, "%d host threads (contexts) per GPU" % T if not batched
                               else "%d worker threads / streams per GPU inside the library (one launch sequence per query)" % T if select == SELECT_INLIERS
-                              else "all queries of a GPU share their launches (rounds of 64, 128, ... steps, list of running queries kept on the device)"),
+                              else "all queries of a GPU share their launches (rounds of 128, 640, 3200, ... steps, list of running queries kept on the device)"),
                           "queries": "resident in HBM (pose_amd_batch_create before the timed region, pose_amd_batch_run timed)" if resident is not None
                                      else "host arrays handed over in every pass (packing + PCIe copy inside the timed region)",
                           "hypotheses_per_s": round(steps_total * args.steps / dt, 1),
@@ -548,7 +548,7 @@ def roofline_shared_launches(resident, queries, res, sample_mode, select, args):
                "steps_computed": t["p3p_steps_computed"] + t["p4pf_steps_computed"], "poses_painted": t["poses_painted"],
                "pairs_scored": round(pairs, 1),
                "note": "HIP events after every launch of one run of the resident list (outside the timed region); kernel_ms_per_step is that run's "
-                       "sum per kernel; steps_computed counts the speculative rounds (64, 128, 256, ... steps for every query still running)"})
+                       "sum per kernel; steps_computed counts the speculative rounds (128, 640, 3200, ... steps for every query still running)"})
     return rl
 
 

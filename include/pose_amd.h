@@ -165,7 +165,7 @@ typedef struct {
  * [+ set_camsets] + pose_amd_sample(sample_mode, seed, query_id, 0, budget) +
  * pose_amd_ransac_run(params), with bit-identical results.
  * With the reference's selection (POSE_AMD_SELECT_COVERAGE) all queries share their launches:
- * rounds of 64, 128, 256, ... RANSAC steps run for every query whose loop has not ended, the
+ * rounds of 128, 640, 3 200, ... RANSAC steps run for every query whose loop has not ended, the
  * device keeps that list itself and the host waits once, at the end.  With inlier-count selection
  * (or POSE_AMD_BATCH=threads in the environment) internal worker threads, each with its own
  * stream (count from POSE_AMD_BATCH_LANES, default 8), run one launch sequence per query.

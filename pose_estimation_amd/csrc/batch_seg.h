@@ -29,6 +29,8 @@ struct seg_query {
     int separable;               // the row-union coverage kernel fits this image
     int bm_words;                // advanced sampler: words of the camera bitmap, 0 = merge lists
     int cv_rows;                 // output rows per pass of k_seg_cover_pose, 0: the query's areas come from k_seg_coverage
+    const uint4 *feat;           // feature image of the matrix-core screen (score_mfma.h), null: not built
+    query_centre qc;             // centre of the 3-D points and largest distance from it
 };
 
 // what a launch needs to find its query and its segment
@@ -144,6 +146,75 @@ __global__ __launch_bounds__(SCORE_THREADS) __attribute__((amdgpu_waves_per_eu(6
     const size_t base = (size_t)blockIdx.y * L.S, sbase = base * maxsol;
     score_screen_block<false>(seg_of(L, blockIdx.y).q, L.V * maxsol, proj + sbase * 12, projf + sbase * 32, nsol + base, maxsol, eps, counts + sbase,
                               nullptr, 0, spb, blockIdx.x, s_cnt, s_list, s_wave_n);
+}
+
+// ---- scoring on the matrix cores (score_mfma.h) --------------------------------------------------------
+// feature images of all queries of a list: blockIdx.y = query
+__global__ void k_seg_make_feat(const seg_query *__restrict__ qt)
+{
+    const seg_query &sq = qt[blockIdx.y];
+    if (!sq.feat) return;
+    make_feat_entry(sq.q, sq.qc, (sq.q.n + 31) / 32, const_cast<uint4 *>(sq.feat), blockIdx.x * blockDim.x + threadIdx.x);
+}
+
+// Dense list of a query's valid pose slots (order unspecified), as k_compact_valid builds it for one
+// query: vlist[segment of the query], vcount[position] (zeroed before the launch); the counts of
+// the other slots are set to 0.
+__global__ __launch_bounds__(256) void k_seg_compact_valid(seg_launch L, int maxsol, const int *__restrict__ nsol, int *__restrict__ vlist,
+                                                            unsigned int *__restrict__ vcount, int *__restrict__ counts)
+{
+    __shared__ int s_n[4];
+    __shared__ unsigned s_base;
+    const int a = blockIdx.y;
+    if (!seg_live(L, a)) return;
+    const int nslots = L.V * maxsol;
+    if ((int)blockIdx.x * MS_COMPACT_SLOTS >= nslots) return;
+    const size_t base = (size_t)a * L.S, sbase = base * maxsol;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int slot0 = blockIdx.x * MS_COMPACT_SLOTS + threadIdx.x;
+    unsigned valid = 0;
+#pragma unroll
+    for (int k = 0; k < MS_COMPACT_SLOTS / 256; ++k) {
+        const int slot = slot0 + 256 * k;
+        const bool ok = slot < nslots && (slot % maxsol) < nsol[base + slot / maxsol];
+        if (ok) valid |= 1u << k;
+        if (slot < nslots && !ok) counts[sbase + slot] = 0;
+    }
+    const int mine = __popc(valid);
+    int incl = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(incl, o);
+        if (lane >= o) incl += v;
+    }
+    if (lane == 63) s_n[wave] = incl;
+    __syncthreads();
+    if (threadIdx.x == 0) s_base = atomicAdd(&vcount[a], (unsigned)(s_n[0] + s_n[1] + s_n[2] + s_n[3]));
+    __syncthreads();
+    int off = (int)s_base + incl - mine;
+    for (int w = 0; w < 4; ++w) if (w < wave) off += s_n[w];
+#pragma unroll
+    for (int k = 0; k < MS_COMPACT_SLOTS / 256; ++k)
+        if ((valid >> k) & 1u) vlist[sbase + off++] = slot0 + 256 * k;
+}
+
+// k_score_mfma for the queries of a pass: blockIdx.y = position, blockIdx.x = batch of 64 WAVES valid
+// poses of that query.  Blocks are small (two or four waves) because a round of 64 steps gives a
+// query about a hundred valid poses.
+template <int WAVES, int CHUNK>
+__global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_seg_score_mfma(seg_launch L, int maxsol, const double *__restrict__ proj,
+                                                                                                          const int *__restrict__ vlist,
+                                                                                                          const unsigned int *__restrict__ vcount, double eps,
+                                                                                                          int *__restrict__ counts)
+{
+    const int a = blockIdx.y;
+    if (!seg_live(L, a)) return;
+    const int nvalid = (int)vcount[a], first = (int)blockIdx.x * (WAVES * 64);
+    if (first >= nvalid) return;
+    const seg_query &sq = seg_of(L, a);
+    const size_t sbase = (size_t)a * L.S * maxsol;
+    score_mfma_core<WAVES, CHUNK>(sq.q, sq.qc, sq.feat, 0, (sq.q.n + 31) / 32, 1, 0, proj + sbase * 12, vlist + sbase, nvalid, first, eps, counts + sbase, nullptr,
+                                  nullptr);
 }
 
 // ---- coverage-quality selection, one block per query -----------------------------------------------

@@ -91,7 +91,7 @@ struct pose_amd_ctx {
     std::vector<pose_amd_ctx *> lanes;
     struct pose_amd_batch *own_batch = nullptr;   // resident list behind pose_amd_ransac_batch
     // segmented batch (many queries per launch): packed queries, descriptor table, per-hypothesis arrays, selection scratch
-    dev_buf sg_samples, sg_sstatus, sg_arows, sg_pstatus, sg_proj, sg_pose, sg_projf, sg_nsol, sg_counts, sg_n,
+    dev_buf sg_vlist, sg_vcount, sg_samples, sg_sstatus, sg_arows, sg_pstatus, sg_proj, sg_pose, sg_projf, sg_nsol, sg_counts, sg_n,
         sg_list1, sg_area1, sg_bands1, sg_list2, sg_bands2, sg_mslot, sg_marea, sg_mkeep, sg_allsums;
     pin_buf sgh_allsums;
     // hypotheses
@@ -278,7 +278,7 @@ void pose_amd_destroy(pose_amd_ctx *c)
                        &c->sample_status, &c->proj, &c->pose, &c->nsol, &c->counts, &c->sel, &c->bitmaps, &c->areas,
                        &c->maskw, &c->arows, &c->pstatus, &c->projf, &c->feat, &c->vlist, &c->vcount, &c->arows2, &c->pstatus2, &c->vlist2, &c->vcount2, &c->in0, &c->in1, &c->in2, &c->out0, &c->out1, &c->out2, &c->out3,
                        &c->cov_state, &c->cov_n, &c->cov_list1, &c->cov_bands1, &c->cov_area1, &c->cov_list2, &c->cov_bands2, &c->cov_mslot, &c->cov_marea,
-                       &c->cov_mkeep, &c->sg_samples, &c->sg_sstatus, &c->sg_arows, &c->sg_pstatus, &c->sg_proj,
+                       &c->cov_mkeep, &c->sg_vlist, &c->sg_vcount, &c->sg_samples, &c->sg_sstatus, &c->sg_arows, &c->sg_pstatus, &c->sg_proj,
                        &c->sg_pose, &c->sg_projf, &c->sg_nsol, &c->sg_counts, &c->sg_n, &c->sg_list1, &c->sg_area1, &c->sg_bands1, &c->sg_list2,
                        &c->sg_bands2, &c->sg_mslot, &c->sg_marea, &c->sg_mkeep, &c->sg_allsums};
     for (dev_buf *b : bufs) if (b->p) (void)hipFree(b->p);
@@ -1110,6 +1110,12 @@ int pose_amd_ransac_run(pose_amd_ctx *ctx, const pose_amd_params *prm, pose_amd_
 
 
 // ---- many queries, segmented launches ------------------------------------------------------------
+#ifndef SEG_MFMA_WAVES
+#define SEG_MFMA_WAVES 4
+#endif
+#ifndef SEG_MFMA_CHUNK
+#define SEG_MFMA_CHUNK 16
+#endif
 // Coverage geometry of an image.
 // The multi-query launches have blocks enough from the queries alone, so their bands are thick (six
 // per image where the LDS allows): fewer painted rows above each band, fewer scans of the query.
@@ -1146,7 +1152,8 @@ struct pose_amd_batch {
     pin_buf hpack;                            // page-locked: the upload reads it directly
     std::vector<seg_query> qt;                // host copy of the table (thresh is filled in per run)
     std::vector<int64_t> area_all;
-    dev_buf qpack, qtab, lists, state, totals;
+    dev_buf qpack, qtab, lists, state, totals, feat;
+    bool mfma_ok = false;                     // every query has a feature image: the rounds score on the matrix cores
     pin_buf h_qtab, h_lists, h_out;
     int bands_max = 1, bm_max = 0;
     size_t lds_cov = 0, lds_pose = 0;         // dynamic LDS of k_seg_coverage / k_seg_cover_pose (0: no query uses the latter)
@@ -1160,7 +1167,7 @@ struct pose_amd_batch {
 static void batch_free(pose_amd_batch *b)
 {
     if (!b) return;
-    dev_buf *bufs[] = {&b->qpack, &b->qtab, &b->lists, &b->state, &b->totals};
+    dev_buf *bufs[] = {&b->qpack, &b->qtab, &b->lists, &b->state, &b->totals, &b->feat};
     for (dev_buf *d : bufs) if (d->p) { (void)hipFree(d->p); d->p = nullptr; d->cap = 0; }
     pin_buf *pins[] = {&b->hpack, &b->h_qtab, &b->h_lists, &b->h_out};
     for (pin_buf *d : pins) if (d->p) { (void)hipHostFree(d->p); d->p = nullptr; d->cap = 0; }
@@ -1264,6 +1271,16 @@ static int batch_fill(pose_amd_ctx *ctx, pose_amd_batch *b, int nq, const pose_a
                     xm = std::fmax(xm, a); um = std::fmax(um, u);
                 }
                 sq.q.xmax = finite ? xm : NAN; sq.q.umax = finite ? um * 1.000001f : NAN;
+                {   // centre of the 3-D points and the largest distance from it along an axis (matrix-core screen), as in set_query
+                    double sx = 0, sy = 0, sz = 0;
+                    for (int k = 0; k < q.n; ++k) { sx += q.X[k]; sy += q.Y[k]; sz += q.Z[k]; }
+                    const float cx = (float)(sx / q.n), cy = (float)(sy / q.n), cz = (float)(sz / q.n);
+                    double dm = 0;
+                    for (int k = 0; k < q.n; ++k)
+                        dm = std::fmax(dm, std::fmax(std::fabs((double)q.X[k] - cx), std::fmax(std::fabs((double)q.Y[k] - cy), std::fabs((double)q.Z[k] - cz))));
+                    const bool cfin = finite && std::isfinite(cx) && std::isfinite(cy) && std::isfinite(cz) && std::isfinite(dm);
+                    sq.qc = query_centre{cx, cy, cz, cfin ? (float)(dm * 1.000001) : NAN};
+                }
                 sq.query_id = q.query_id;
                 sq.maxsol = q.focal == 0.0 ? P4PF_MAXSOL : P3P_MAXSOL;
                 const long long cover = (long long)std::ceil((float)q.width / 20.0f);
@@ -1314,9 +1331,33 @@ static int batch_fill(pose_amd_ctx *ctx, pose_amd_batch *b, int nq, const pose_a
         b->bands_max = std::max(b->bands_max, b->qt[(size_t)i].bands);
         b->bm_max = std::max(b->bm_max, b->qt[(size_t)i].bm_words);
     }
+    // feature images of the matrix-core screen: all queries or none
+    b->mfma_ok = ctx->score_mfma && !ctx->score_fp64_only;
+    size_t feat_bytes = 0;
+    int ntiles_max = 1;
+    for (int i = 0; i < nq; ++i) {
+        const seg_query &sq = b->qt[(size_t)i];
+        b->mfma_ok = b->mfma_ok && sq.q.n <= MS_MAX_N - 32 && sq.qc.xmaxc == sq.qc.xmaxc && sq.q.umax == sq.q.umax;
+        feat_bytes += (size_t)cdiv(sq.q.n, 32) * MS_TILE_BYTES;
+        ntiles_max = std::max(ntiles_max, cdiv(sq.q.n, 32));
+    }
+    if (b->mfma_ok) {
+        if ((rc = ensure(ctx, b->feat, feat_bytes))) return rc;
+        size_t off = 0;
+        for (int i = 0; i < nq; ++i) {
+            b->qt[(size_t)i].feat = (const uint4 *)((const char *)b->feat.p + off);
+            off += (size_t)cdiv(b->qt[(size_t)i].q.n, 32) * MS_TILE_BYTES;
+        }
+    }
     HIPCHK(ctx, hipMemcpyAsync(b->qpack.p, b->hpack.p, total, hipMemcpyHostToDevice, ctx->stream));
     memcpy(b->h_qtab.p, b->qt.data(), (size_t)nq * sizeof(seg_query));
     HIPCHK(ctx, hipMemcpyAsync(b->qtab.p, b->h_qtab.p, (size_t)nq * sizeof(seg_query), hipMemcpyHostToDevice, ctx->stream));
+    if (b->mfma_ok) {
+        for (int g0 = 0; g0 < nq; g0 += 32768)
+            hipLaunchKernelGGL(k_seg_make_feat, dim3(cdiv(ntiles_max * 32, 256), (unsigned)std::min(32768, nq - g0)), dim3(256), 0, ctx->stream,
+                               (const seg_query *)b->qtab.p + g0);
+        HIPCHK(ctx, hipGetLastError());
+    }
     // all-matches areas (query_processor.cpp:154-169): every query is "active", the list is the identity
     int *hl = (int *)b->h_lists.p;
     for (int i = 0; i < nq; ++i) hl[i] = i;
@@ -1341,7 +1382,7 @@ static int batch_fill(pose_amd_ctx *ctx, pose_amd_batch *b, int nq, const pose_a
 }
 
 // QueryProcessorBasic/Advanced::Process for the queries of a resident list with the reference's
-// selection (coverage quality), many queries per launch.  Rounds of 64, 128, 256, ... steps; the
+// selection (coverage quality), many queries per launch.  Rounds of 128, 640, 3 200, ... steps; the
 // device keeps the list of queries whose loop has not ended (k_seg_compact) and the host issues
 // every round without waiting: one download of the per-query outcome ends the call.  Results equal
 // the per-query sequence set_query + sample + ransac_run.  fallback[i] is set for queries that must
@@ -1410,8 +1451,10 @@ static int batch_run_segmented(pose_amd_batch *b, int sample_mode, uint64_t seed
         if (sscanf(e, "%d,%d", &a1, &a2) == 2 && a1 > 0 && a2 > 0) { cap1 = std::min(a1, cap1); cap2 = std::min(a2, cap2); }
     }
     // With early exit most queries end long before the budget does, and every step of a round behind a
-    // query's last one is wasted: rounds start short and double.
-    uint32_t first_len = 64u, growth = 2u;
+    // query's last one is wasted: rounds start short (128 steps) and grow fivefold -- few enough rounds
+    // that the small launches of the late ones, which are all latency, do not add up (measured on the
+    // Dubrovnik-shaped batch: 64,2 / 128,3 / 128,5 / 128,8 give 80 / 93 / 97 / 83 thousand queries per second).
+    uint32_t first_len = 128u, growth = 5u;
     if (const char *e = getenv("POSE_AMD_SEG_ROUNDS")) {
         unsigned a1 = 0, a2 = 0;
         if (sscanf(e, "%u,%u", &a1, &a2) == 2 && a1 >= 16 && a2 >= 2) { first_len = std::min(a1, 16384u); growth = std::min(a2, 16u); }
@@ -1421,6 +1464,12 @@ static int batch_run_segmented(pose_amd_batch *b, int sample_mode, uint64_t seed
     size_t pass_bytes = (size_t)4 << 30;
     if (const char *e = getenv("POSE_AMD_SEG_PASS_MB")) pass_bytes = (size_t)std::max(16, atoi(e)) << 20;
     const int bands_max = b->bands_max;
+    static const bool seg_packed = getenv("POSE_AMD_SEG_SCORE") && strcmp(getenv("POSE_AMD_SEG_SCORE"), "packed") == 0;
+    // The matrix-core screen pays where nearly all poses are junk (the random tuples of the basic
+    // sampler); the co-occurrence sampler returns many poses with hundreds of inliers, whose pairs
+    // the screen cannot certify, and the packed float32 screen is the faster one there.
+    static const bool seg_mfma_always = getenv("POSE_AMD_SEG_SCORE") && strcmp(getenv("POSE_AMD_SEG_SCORE"), "mfma") == 0;
+    const bool use_mfma = b->mfma_ok && !seg_packed && (!advanced || seg_mfma_always);
     // blocks per (query, band) of the two coverage launches of a pass (records, candidates): every block
     // scans the query's correspondences once, so few blocks with several poses each
     // k_seg_cover_pose: blocks per query that share the list's poses round-robin (records, candidates) and
@@ -1464,7 +1513,7 @@ static int batch_run_segmented(pose_amd_batch *b, int sample_mode, uint64_t seed
                 seg_launch L{(const seg_query *)b->qtab.p, (const int *)active_dev[solver], (const int *)nact_dev[solver], a0, S, (int)valid, step0};
                 uint32_t *samples = (uint32_t *)ctx->sg_samples.p;
                 double *proj = (double *)ctx->sg_proj.p, *pose = (double *)ctx->sg_pose.p;
-                float *projf = (float *)ctx->sg_projf.p;
+                float *projf = use_mfma ? nullptr : (float *)ctx->sg_projf.p;      // the float32 pose copies serve the packed screen only
                 int *nsol = (int *)ctx->sg_nsol.p, *counts = (int *)ctx->sg_counts.p;
                 if (advanced)
                     hipLaunchKernelGGL(k_seg_sample_advanced, dim3(cdiv(valid, SAMPLE_ADV_WAVES), (unsigned)na), dim3(64 * SAMPLE_ADV_WAVES),
@@ -1488,11 +1537,22 @@ static int batch_run_segmented(pose_amd_batch *b, int sample_mode, uint64_t seed
                                        prm->eps);
                     if ((rc = mark(1))) return rc;
                 }
-                // slots per block as in launch_score: as many as possible while the launch keeps about four blocks per compute unit
-                int spb = SCORE_SPB;
-                while (spb > 8 && (long long)na * cdiv((long long)valid * maxsol, spb) < (ctx->cus ? ctx->cus : 256) * 4) spb >>= 1;
-                hipLaunchKernelGGL(k_seg_score_screen, dim3(cdiv((long long)valid * maxsol, spb), (unsigned)na), dim3(SCORE_THREADS), 0, ctx->stream, L, maxsol,
-                                   (const double *)proj, (const float *)projf, (const int *)nsol, prm->eps, counts, spb);
+                if (use_mfma) {
+                    // the matrix-core screen: list of the valid slots of every query, then blocks of two waves (128 poses)
+                    if ((rc = ensure(ctx, ctx->sg_vlist, ns * 4)) || (rc = ensure(ctx, ctx->sg_vcount, na * 4))) return rc;
+                    HIPCHK(ctx, hipMemsetAsync(ctx->sg_vcount.p, 0, na * 4, ctx->stream));
+                    hipLaunchKernelGGL(k_seg_compact_valid, dim3(cdiv((long long)valid * maxsol, MS_COMPACT_SLOTS), (unsigned)na), dim3(256), 0, ctx->stream, L, maxsol,
+                                       (const int *)nsol, (int *)ctx->sg_vlist.p, (unsigned int *)ctx->sg_vcount.p, counts);
+                    hipLaunchKernelGGL((k_seg_score_mfma<SEG_MFMA_WAVES, SEG_MFMA_CHUNK>), dim3(cdiv((long long)valid * maxsol, SEG_MFMA_WAVES * 64), (unsigned)na),
+                                       dim3(SEG_MFMA_WAVES * 64), 0, ctx->stream, L, maxsol, (const double *)proj, (const int *)ctx->sg_vlist.p,
+                                       (const unsigned int *)ctx->sg_vcount.p, prm->eps, counts);
+                } else {
+                    // slots per block as in launch_score: as many as possible while the launch keeps about four blocks per compute unit
+                    int spb = SCORE_SPB;
+                    while (spb > 8 && (long long)na * cdiv((long long)valid * maxsol, spb) < (ctx->cus ? ctx->cus : 256) * 4) spb >>= 1;
+                    hipLaunchKernelGGL(k_seg_score_screen, dim3(cdiv((long long)valid * maxsol, spb), (unsigned)na), dim3(SCORE_THREADS), 0, ctx->stream, L, maxsol,
+                                       (const double *)proj, (const float *)projf, (const int *)nsol, prm->eps, counts, spb);
+                }
                 if ((rc = mark(4))) return rc;
                 seg_cov C{(unsigned long long *)b->state.p, (int *)ctx->sg_n.p, (int *)ctx->sg_list1.p, (long long *)ctx->sg_area1.p,
                           (unsigned long long *)ctx->sg_bands1.p, cap1, (int *)ctx->sg_list2.p, (unsigned long long *)ctx->sg_bands2.p, cap2,

@@ -222,55 +222,42 @@ __device__ __forceinline__ bool ms_exact_inlier(const query_dev &q, const double
     return d2 < te * te;
 }
 
-// counts[slot] for the valid slots listed in vlist[0 .. *nvalid_p).  One block takes MS_POSES
-// consecutive entries of the list; wave w owns the groups 2w and 2w + 1 of 32 poses each and keeps
-// their operands in registers while the block walks over the correspondences in chunks of
-// MS_CHUNK_TILES tiles staged in LDS.  Both groups share the tile's feature operands; the six
-// matrix instructions of a tile are issued back to back so that the vector work on the first
-// group's result overlaps the second group's products.
-__global__ __launch_bounds__(MS_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_score_mfma(
-    query_dev q, query_centre qc, const uint4 *__restrict__ feat, int ntiles, int tiles_per_block, const double *__restrict__ proj,
-    const int *__restrict__ vlist, unsigned int *__restrict__ nvalid_p, double eps, int *__restrict__ counts,
-    unsigned long long *__restrict__ sel)
+// counts[slot] for the valid slots listed in vlist[0 .. nvalid).  One block takes POSES = 64 WAVES
+// consecutive entries of the list, from `first` on; wave w owns the groups 2w and 2w + 1 of 32 poses
+// each and keeps their operands in registers while the block walks over the tiles [tile_begin,
+// tile_end) of the query's feature image in chunks of CHUNK tiles staged in LDS.  Both groups share
+// the tile's feature operands; the six matrix instructions of a tile are issued back to back so
+// that the vector work on the first group's result overlaps the second group's products.
+// nshare > 1: that many blocks share these poses along the correspondences (block `batch` of the
+// launch's pose batches); their counts are added up with atomics and batch_done orders them.
+template <int WAVES, int CHUNK>
+__device__ __forceinline__ void score_mfma_core(const query_dev &q, const query_centre &qc, const uint4 *__restrict__ feat, int tile_begin, int tile_end,
+                                                int nshare, int batch, const double *__restrict__ proj, const int *__restrict__ vlist, int nvalid,
+                                                int first, double eps, int *__restrict__ counts, unsigned long long *__restrict__ sel,
+                                                unsigned int *__restrict__ batch_done)
 {
-    __shared__ uint4 s_feat[MS_CHUNK_TILES * MS_TILE_BYTES / 16];
-    __shared__ int s_cnt[MS_POSES];
-    __shared__ int s_slot[MS_POSES];
-    __shared__ int s_dense[MS_POSES];                       // first correspondence of the pose's float64 scan
-    __shared__ unsigned s_queue[MS_WAVES][MS_QUEUE + 64];   // + one scratch word per lane
+    constexpr int THREADS = WAVES * 64, POSES = WAVES * MS_GROUPS * 32;
+
+    __shared__ uint4 s_feat[CHUNK * MS_TILE_BYTES / 16];
+    __shared__ int s_cnt[POSES];
+    __shared__ int s_slot[POSES];
+    __shared__ int s_dense[POSES];                          // first correspondence of the pose's float64 scan
+    __shared__ unsigned s_queue[WAVES][MS_QUEUE + 64];      // + one scratch word per lane
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const bool upper = lane >= 32;
-    static_assert(MS_POSES == MS_THREADS, "one slot-list entry per thread");
-    const int first = blockIdx.x * MS_POSES;
+    static_assert(POSES == THREADS, "one slot-list entry per thread");
     const int pl0 = wave * (32 * MS_GROUPS) + (lane & 31);    // the lane's pose of group 0; group g: + 32 g
-    const int nvalid = (int)*nvalid_p;
-    // The grid covers all slots, valid or not: most blocks of a launch with few valid poses
-    // leave here, before they have asked memory for anything else.
-    if (first >= nvalid) return;
-    // nvalid_p[1] counts the blocks with poses that are done; the last one zeroes both words for
-    // the next launch on this stream (every block has read the count by then)
-    auto leave = [&]() {
-        const unsigned working = (unsigned)((nvalid + MS_POSES - 1) / MS_POSES) * gridDim.y;
-        if (tid == 0 && atomicAdd(&nvalid_p[1], 1u) == working - 1) {
-            __hip_atomic_store(&nvalid_p[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(&nvalid_p[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    };
-    const int nblk = min(MS_POSES, nvalid - first);
+    const int nblk = min(POSES, nvalid - first);
     int myslot[MS_GROUPS];
 #pragma unroll
     for (int g = 0; g < MS_GROUPS; ++g) myslot[g] = pl0 + 32 * g < nblk ? vlist[first + pl0 + 32 * g] : 0;
     s_cnt[tid] = 0;
     s_dense[tid] = 0x7fffffff;
     s_slot[tid] = tid < nblk ? vlist[first + tid] : -1;
-    // blockIdx.y selects the block's share of the correspondences (small launches are spread over
-    // the chip that way; the counts of a pose are then added up from several blocks)
-    const int tile_begin = (int)blockIdx.y * tiles_per_block;
-    const int tile_end = min(ntiles, tile_begin + tiles_per_block);
     auto stage = [&](int chunk0, int ct) {
-        for (int i = tid; i < ct * (MS_TILE_BYTES / 16); i += MS_THREADS) s_feat[i] = feat[(size_t)chunk0 * (MS_TILE_BYTES / 16) + i];
+        for (int i = tid; i < ct * (MS_TILE_BYTES / 16); i += THREADS) s_feat[i] = feat[(size_t)chunk0 * (MS_TILE_BYTES / 16) + i];
     };
-    stage(tile_begin, min(MS_CHUNK_TILES, tile_end - tile_begin));   // in flight together with the poses
+    stage(tile_begin, min(CHUNK, tile_end - tile_begin));   // in flight together with the poses
     ms_pose_ops ops[MS_GROUPS];
     const bool live = wave * (32 * MS_GROUPS) < nblk;         // wave-uniform: the wave has at least one pose
 #pragma unroll
@@ -353,8 +340,8 @@ __global__ __launch_bounds__(MS_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
         }
     };
 
-    for (int chunk0 = tile_begin; chunk0 < tile_end; chunk0 += MS_CHUNK_TILES) {
-        const int ct = min(MS_CHUNK_TILES, tile_end - chunk0);
+    for (int chunk0 = tile_begin; chunk0 < tile_end; chunk0 += CHUNK) {
+        const int ct = min(CHUNK, tile_end - chunk0);
         if (chunk0 != tile_begin) {                      // the first chunk was staged before the poses were prepared
             __syncthreads();                             // everybody is done with the previous chunk
             stage(chunk0, ct);
@@ -413,37 +400,60 @@ __global__ __launch_bounds__(MS_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
         if (lane == 0) s_key[wave] = key;
         __syncthreads();
         if (tid == 0) {
-            for (int w = 1; w < MS_WAVES; ++w) key = s_key[w] > key ? s_key[w] : key;
+            for (int w = 1; w < WAVES; ++w) key = s_key[w] > key ? s_key[w] : key;
             atomicMax(&sel[0], key);
             atomicAdd(&sel[2], (unsigned long long)nblk);
         }
     };
-    if (gridDim.y == 1) {
-        for (int i = tid; i < nblk; i += MS_THREADS) counts[s_slot[i]] = s_cnt[i];
+    if (nshare == 1) {
+        for (int i = tid; i < nblk; i += THREADS) counts[s_slot[i]] = s_cnt[i];
         if (sel) publish_best(s_cnt[tid]);
     } else {
         // The counts of a pose are added up by device-scope atomics from the blocks that share it.
-        for (int i = tid; i < nblk; i += MS_THREADS)
+        for (int i = tid; i < nblk; i += THREADS)
             if (s_cnt[i]) atomicAdd(&counts[s_slot[i]], s_cnt[i]);
         if (sel) {
-            // the block that finishes last among those that share these poses (nvalid_p[2 + x]
+            // the block that finishes last among those that share these poses (batch_done[batch]
             // counts them and is left at zero again) reads the summed counts and publishes.
             // Ordering: the barrier orders the block's adds before thread 0's increment of the
             // group's counter, which is a release (this block's adds are visible to whoever reads
             // the counter) and an acquire (the last block sees the adds of all earlier ones) at
             // device scope; the second barrier hands that on to the block's other threads.
-            unsigned int *batch_done = nvalid_p + 2;
             __syncthreads();
             if (tid == 0)
-                s_dense[0] = __hip_atomic_fetch_add(&batch_done[blockIdx.x], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.y - 1 ? 1 : 0;   // s_dense is free by now
+                s_dense[0] = __hip_atomic_fetch_add(&batch_done[batch], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)nshare - 1u ? 1 : 0;   // s_dense is free by now
             __syncthreads();
             if (s_dense[0]) {
-                if (tid == 0) __hip_atomic_store(&batch_done[blockIdx.x], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (tid == 0) __hip_atomic_store(&batch_done[batch], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 publish_best(tid < nblk ? __hip_atomic_load(&counts[s_slot[tid]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0);
             }
         }
     }
-    leave();
+}
+
+
+// The launch of one query: blockIdx.x = batch of MS_POSES entries of the slot list, blockIdx.y = the
+// block's share of the correspondences (small launches are spread over the chip that way).
+__global__ __launch_bounds__(MS_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_score_mfma(
+    query_dev q, query_centre qc, const uint4 *__restrict__ feat, int ntiles, int tiles_per_block, const double *__restrict__ proj,
+    const int *__restrict__ vlist, unsigned int *__restrict__ nvalid_p, double eps, int *__restrict__ counts,
+    unsigned long long *__restrict__ sel)
+{
+    const int first = blockIdx.x * MS_POSES;
+    const int nvalid = (int)*nvalid_p;
+    // The grid covers all slots, valid or not: most blocks of a launch with few valid poses
+    // leave here, before they have asked memory for anything else.
+    if (first >= nvalid) return;
+    const int tile_begin = (int)blockIdx.y * tiles_per_block;
+    score_mfma_core<MS_WAVES, MS_CHUNK_TILES>(q, qc, feat, tile_begin, min(ntiles, tile_begin + tiles_per_block), (int)gridDim.y, (int)blockIdx.x, proj, vlist,
+                                              nvalid, first, eps, counts, sel, nvalid_p + 2);
+    // nvalid_p[1] counts the blocks with poses that are done; the last one zeroes both words for
+    // the next launch on this stream (every block has read the count by then)
+    const unsigned working = (unsigned)((nvalid + MS_POSES - 1) / MS_POSES) * gridDim.y;
+    if (threadIdx.x == 0 && atomicAdd(&nvalid_p[1], 1u) == working - 1) {
+        __hip_atomic_store(&nvalid_p[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&nvalid_p[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
 } // namespace pose_amd
