@@ -58,8 +58,10 @@ def parse_args():
     ap.add_argument("--known-focal", action="store_true", help="single: P3P instead of P4Pf (BASELINE configs[0] shape with --matches 2000 --inlier-frac 0.3)")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="process-group backend; gloo (CPU tensors) lets several ranks rehearse on one GPU")
-    ap.add_argument("--workload", choices=["single", "dubrovnik"], default="single",
-                    help="single: BASELINE configs[1] (default, the headline line); dubrovnik: configs[2], 800 queries sharded by query")
+    ap.add_argument("--workload", choices=["single", "dubrovnik", "knn"], default="single",
+                    help="single: BASELINE configs[1] (default, the headline line); dubrovnik: configs[2], 800 queries sharded by query; "
+                         "knn: the descriptor matching in front of the path (2-NN + ratio test of --queries descriptors against --points model points)")
+    ap.add_argument("--points", type=int, default=1 << 20, help="knn: model points")
     ap.add_argument("--queries", type=int, default=800)
     ap.add_argument("--budget", type=int, default=10000, help="dubrovnik: hypotheses per query")
     ap.add_argument("--early-exit", action="store_true", help="dubrovnik: the reference's loop (coverage quality, stop at 12 inliers)")
@@ -130,6 +132,8 @@ def main():
         return self_launch(args)
     if args.workload == "dubrovnik":
         return bench_dubrovnik(args)
+    if args.workload == "knn":
+        return bench_knn(args)
     rank, world, dev_index, red_dev, torch, dist = setup_ranks(args)
 
     from pose_estimation_amd import Context, shard, synth, SELECT_INLIERS, SAMPLE_BASIC
@@ -492,6 +496,82 @@ def bench_dubrovnik(args):
         resident.close()
     for c in ctxs:
         c.close()
+    if world > 1:
+        dist.destroy_process_group()
+    return 0
+
+
+def bench_knn(args):
+    """The matching step in front of the path: one pass = pose_amd_knn_match of --queries uint8
+    descriptors (default 8192) against a model of --points averaged descriptors resident in HBM
+    (the reference's FLANN search, query_processor_basic.cpp:60-96, done exactly).  Replicas only:
+    with --gpus N every rank searches its own query descriptors against its own copy of the model."""
+    rank, world, dev_index, red_dev, torch, dist = setup_ranks(args)
+    from pose_estimation_amd import Context, synth_desc
+    nq = args.queries if args.queries != 800 else 8192
+    rng = np.random.default_rng(17)
+    # model descriptors straight as floats (SIFT-like norms); a share of the queries are noisy copies
+    model = synth_desc.make_model(min(args.points, 1 << 16), seed=21)
+    proto = model["proto"].astype(np.float32)
+    feat = proto[rng.integers(0, len(proto), args.points)] + rng.normal(0.0, 12.0, (args.points, 128)).astype(np.float32)
+    feat = np.clip(feat, 0, 255).astype(np.float32)
+    pick = rng.integers(0, args.points, nq)
+    q = np.clip(np.rint(feat[pick] + rng.normal(0.0, 6.0, (nq, 128))), 0, 255).astype(np.uint8)
+    q[nq // 2:] = np.clip(np.rint(synth_desc._sift_like(rng, nq - nq // 2)), 0, 255).astype(np.uint8)
+    ctx = Context(dev_index)
+    ctx.knn_set_model(feat)
+
+    def sync():
+        ctx.synchronize()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        r = ctx.knn_match(q, 0.7)
+    sync()
+    t0 = time.perf_counter()
+    ms = {}
+    for _ in range(args.steps):
+        r = ctx.knn_match(q, 0.7)
+        for k, v in ctx.knn_last_timing().items():
+            ms[k] = ms.get(k, 0.0) + v
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=red_dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    if rank == 0:
+        pairs = float(nq) * args.points
+        scan_s = ms["scan_ms"] / args.steps * 1e-3
+        executed = pairs * 2 * 128 * 2 / scan_s / 1e12               # two bfloat16 parts of every model descriptor
+        out = {"metric": "query descriptors matched per second (exact 2-NN + ratio test)", "value": round(nq * world * args.steps / dt, 1), "unit": "descriptors/s",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
+               "scaling": "weak", "vs_baseline": None, "dtype": "bf16 x2 (matrix-core scan), f64 (decision)", "data": "synthetic",
+               "config": {"workload": "matching step in front of the path ((f)4): %d uint8 query descriptors against %d averaged float descriptors of 128 "
+                                      "dimensions, 2 nearest by squared L2 and ratio 0.7; replicas only" % (nq, args.points),
+                          "host_transfer": "query descriptors up (%d KB) and results down inside the timed region; the model is resident" % (nq * 128 // 1024),
+                          "pairs_per_s": round(pairs * world * args.steps / dt, 1), "good_matches": int(r["good"].sum()),
+                          "rows_searched_exhaustively": int(r["exhaustive_rows"])},
+               "roofline": {"kernel": "k_knn_scan", "bound": "mfma", "achieved": round(executed, 1), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                            "frac": round(executed / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                            "algorithmic_tflops": round(pairs * 2 * 128 / scan_s / 1e12, 1), "avg_launch_ms": round(scan_s * 1e3, 3),
+                            "kernel_ms_per_step": {k: round(v / args.steps, 3) for k, v in ms.items()},
+                            "note": "executed = 2 x 128 x 2 flop per (query, point) pair: both bfloat16 parts of the model descriptor; algorithmic = one part"}}
+        if not args.no_cpu_baseline:
+            sys.path.insert(0, os.path.join(ROOT, "oracle"))
+            import knn_oracle as K
+            ns = 64
+            t1 = time.perf_counter()
+            K.knn2(feat, q[:ns], 0.7)
+            dtc = time.perf_counter() - t1
+            out["cpu_baseline"] = {"value": round(ns / dtc, 2), "unit": "descriptors/s", "cores": host_cores(), "cpu": cpu_model(), "kind": "port",
+                                   "sample": "the first %d query descriptors against the whole model, oracle/knn_oracle.py (NumPy float64 matrix product "
+                                             "with the BLAS threads of the box, exact re-evaluation of a shortlist), %.1f s" % (ns, dtc)}
+        print(json.dumps(out))
+    ctx.close()
     if world > 1:
         dist.destroy_process_group()
     return 0

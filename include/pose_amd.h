@@ -217,6 +217,30 @@ void pose_amd_multi_release(void);
 int pose_amd_ransac_range(pose_amd_ctx *ctx, int sample_mode, uint64_t seed, uint32_t query_id, uint32_t hyp_begin,
                           uint32_t hyp_count, double eps, pose_amd_result *result, uint64_t *key);
 
+/* ---- descriptor matching in front of the path -------------------------------------------------- */
+/* The model side of QueryProcessorBasic's constructor (query_processor_basic.cpp:22-53): one float
+ * descriptor of 128 dimensions per 3-D point.  pose_amd_knn_set_model takes them as they are
+ * (features[npoints][128]); pose_amd_knn_set_model_views forms them as the reference does, the
+ * float sum of the uint8 SIFT descriptors of a point's views divided by their number
+ * (descriptors[desc_off[npoints]][128], the views of point i are desc_off[i] .. desc_off[i + 1] - 1;
+ * features_out, if not NULL, receives them).  The reference builds a FLANN kd-tree forest here;
+ * this library keeps the descriptors and an image of them for the matrix cores. */
+int pose_amd_knn_set_model(pose_amd_ctx *ctx, int npoints, const float *features);
+int pose_amd_knn_set_model_views(pose_amd_ctx *ctx, int npoints, const uint32_t *desc_off, const unsigned char *descriptors,
+                                 float *features_out);
+/* The search of QueryProcessorBasic::Process (query_processor_basic.cpp:60-96): for each of the nq
+ * query descriptors (uint8[nq][128]) the two nearest model descriptors by squared L2 distance --
+ * indices[nq][2], dists[nq][2] as FLANN's float distances -- and Lowe's ratio test
+ * good[i] = dists[i][0] / dists[i][1] < ratio.  The search is exact (ties: the lower index first),
+ * where the reference's FLANN search (4 trees, 128 checks) is approximate.  exhaustive_rows, if not
+ * NULL, receives the number of rows whose answer the matrix-core scan could not certify and that
+ * were searched exhaustively in float64. */
+int pose_amd_knn_match(pose_amd_ctx *ctx, int nq, const unsigned char *descriptors, float ratio, int *indices, float *dists,
+                       unsigned char *good, int *exhaustive_rows);
+/* HIP-event times of the last pose_amd_knn_match (timing on): ms[0] scan, [1] exact re-evaluation,
+ * [2] exhaustive rows (and the wait for their count), [3] all three. */
+int pose_amd_knn_last_timing(pose_amd_ctx *ctx, float ms[4]);
+
 /* ---- measurement -------------------------------------------------------------------------- */
 /* Kernel time of the last pose_amd_ransac_run measured with HIP events on the context's
  * stream, summed over the call's chunks: ms[0] solve (all solver kernels), ms[1] score,

@@ -78,6 +78,10 @@ SIGNATURES = {
     "pose_amd_multi_last_error": (C.c_char_p, []),
     "pose_amd_multi_release": (None, []),
     "pose_amd_ransac_range": (C.c_int, [_ctx, C.c_int, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_double, C.POINTER(Result), _u64]),
+    "pose_amd_knn_set_model": (C.c_int, [_ctx, C.c_int, _fp]),
+    "pose_amd_knn_set_model_views": (C.c_int, [_ctx, C.c_int, _up, _u8, _fp]),
+    "pose_amd_knn_match": (C.c_int, [_ctx, C.c_int, _u8, C.c_float, _ip, _fp, _u8, _ip]),
+    "pose_amd_knn_last_timing": (C.c_int, [_ctx, C.POINTER(C.c_float)]),
     "pose_amd_last_timing": (C.c_int, [_ctx, C.POINTER(C.c_float)]),
 }
 

@@ -320,6 +320,41 @@ class Context:
         self._chk(self._lib.pose_amd_best_mask(self._h, _ptr(m, _lib._u8)), "best_mask")
         return m
 
+    # ---- descriptor matching ----------------------------------------------------------------
+    def knn_set_model(self, features):
+        """Model descriptors as float32 [npoints, 128] (already averaged over the views)."""
+        f = np.ascontiguousarray(features, dtype=np.float32).reshape(-1, 128)
+        self._chk(self._lib.pose_amd_knn_set_model(self._h, len(f), _ptr(f, _lib._fp)), "knn_set_model")
+
+    def knn_set_model_views(self, desc_off, descriptors):
+        """Model descriptors from the uint8 SIFT descriptors of every point's views (CSR offsets);
+        returns the float32 [npoints, 128] means as the library formed them."""
+        off = _u32(desc_off)
+        d = np.ascontiguousarray(descriptors, dtype=np.uint8).reshape(-1, 128)
+        n = len(off) - 1
+        out = np.zeros((n, 128), dtype=np.float32)
+        self._chk(self._lib.pose_amd_knn_set_model_views(self._h, n, _ptr(off, _lib._up), _ptr(d, _lib._u8), _ptr(out, _lib._fp)), "knn_set_model_views")
+        return out
+
+    def knn_match(self, descriptors, ratio=0.7):
+        """Two nearest model descriptors of every query descriptor (uint8 [nq, 128]) and the ratio
+        test: dict(indices [nq, 2], dists [nq, 2] float32 squared L2, good [nq] bool,
+        exhaustive_rows)."""
+        d = np.ascontiguousarray(descriptors, dtype=np.uint8).reshape(-1, 128)
+        nq = len(d)
+        idx = np.zeros((nq, 2), dtype=np.int32)
+        dist = np.zeros((nq, 2), dtype=np.float32)
+        good = np.zeros(nq, dtype=np.uint8)
+        ex = C.c_int(0)
+        self._chk(self._lib.pose_amd_knn_match(self._h, nq, _ptr(d, _lib._u8), float(ratio), _ptr(idx, _lib._ip), _ptr(dist, _lib._fp), _ptr(good, _lib._u8),
+                                               C.byref(ex)), "knn_match")
+        return dict(indices=idx, dists=dist, good=good.astype(bool), exhaustive_rows=ex.value)
+
+    def knn_last_timing(self):
+        ms = (C.c_float * 4)()
+        self._chk(self._lib.pose_amd_knn_last_timing(self._h, ms), "knn_last_timing")
+        return dict(scan_ms=ms[0], finish_ms=ms[1], exhaustive_ms=ms[2], total_ms=ms[3])
+
     def last_timing(self):
         ms = (C.c_float * 8)()
         self._chk(self._lib.pose_amd_last_timing(self._h, ms), "last_timing")

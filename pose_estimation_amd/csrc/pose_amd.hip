@@ -4,6 +4,7 @@
 #include "../../include/pose_amd.h"
 #include "kernels.h"
 #include "batch_seg.h"
+#include "knn_mfma.h"
 #include <algorithm>
 #include <atomic>
 #include <mutex>
@@ -90,6 +91,10 @@ struct pose_amd_ctx {
     // batch entry point: child contexts (one stream each)
     std::vector<pose_amd_ctx *> lanes;
     struct pose_amd_batch *own_batch = nullptr;   // resident list behind pose_amd_ransac_batch
+    // descriptor matching: model descriptors (float32), their matrix-core image, max |f|; scratch of a search
+    dev_buf knn_feat, knn_image, knn_fmax, knn_q, knn_part_s, knn_part_i, knn_idx, knn_dist, knn_good, knn_flag, knn_in0, knn_in1;
+    int knn_points = 0;
+    float knn_last_ms[4] = {0, 0, 0, 0};
     // segmented batch (many queries per launch): packed queries, descriptor table, per-hypothesis arrays, selection scratch
     dev_buf sg_vlist, sg_vcount, sg_samples, sg_sstatus, sg_arows, sg_pstatus, sg_proj, sg_pose, sg_projf, sg_nsol, sg_counts, sg_n,
         sg_list1, sg_area1, sg_bands1, sg_list2, sg_bands2, sg_mslot, sg_marea, sg_mkeep, sg_allsums;
@@ -278,7 +283,8 @@ void pose_amd_destroy(pose_amd_ctx *c)
                        &c->sample_status, &c->proj, &c->pose, &c->nsol, &c->counts, &c->sel, &c->bitmaps, &c->areas,
                        &c->maskw, &c->arows, &c->pstatus, &c->projf, &c->feat, &c->vlist, &c->vcount, &c->arows2, &c->pstatus2, &c->vlist2, &c->vcount2, &c->in0, &c->in1, &c->in2, &c->out0, &c->out1, &c->out2, &c->out3,
                        &c->cov_state, &c->cov_n, &c->cov_list1, &c->cov_bands1, &c->cov_area1, &c->cov_list2, &c->cov_bands2, &c->cov_mslot, &c->cov_marea,
-                       &c->cov_mkeep, &c->sg_vlist, &c->sg_vcount, &c->sg_samples, &c->sg_sstatus, &c->sg_arows, &c->sg_pstatus, &c->sg_proj,
+                       &c->cov_mkeep, &c->knn_feat, &c->knn_image, &c->knn_fmax, &c->knn_q, &c->knn_part_s, &c->knn_part_i, &c->knn_idx, &c->knn_dist, &c->knn_good,
+                       &c->knn_flag, &c->knn_in0, &c->knn_in1, &c->sg_vlist, &c->sg_vcount, &c->sg_samples, &c->sg_sstatus, &c->sg_arows, &c->sg_pstatus, &c->sg_proj,
                        &c->sg_pose, &c->sg_projf, &c->sg_nsol, &c->sg_counts, &c->sg_n, &c->sg_list1, &c->sg_area1, &c->sg_bands1, &c->sg_list2,
                        &c->sg_bands2, &c->sg_mslot, &c->sg_marea, &c->sg_mkeep, &c->sg_allsums};
     for (dev_buf *b : bufs) if (b->p) (void)hipFree(b->p);
@@ -1794,6 +1800,109 @@ void pose_amd_batch_destroy(pose_amd_batch *b)
     if (!b) return;
     if (b->ctx) (void)hipSetDevice(b->ctx->device);
     batch_free(b);
+}
+
+// ---- descriptor matching (knn_mfma.h) --------------------------------------------------------------------
+static int knn_build_image(pose_amd_ctx *ctx, int npoints)
+{
+    int rc;
+    const int ntiles = cdiv(npoints, 32);
+    if ((rc = ensure(ctx, ctx->knn_image, (size_t)ntiles * KNN_TILE_BYTES)) || (rc = ensure(ctx, ctx->knn_fmax, 4))) return rc;
+    HIPCHK(ctx, hipMemsetAsync(ctx->knn_fmax.p, 0, 4, ctx->stream));
+    hipLaunchKernelGGL(k_knn_make_image, dim3(ntiles), dim3(256), 0, ctx->stream, npoints, (const float *)ctx->knn_feat.p, (uint4 *)ctx->knn_image.p,
+                       (float *)ctx->knn_fmax.p);
+    HIPCHK(ctx, hipGetLastError());
+    ctx->knn_points = npoints;
+    return pose_amd_synchronize(ctx);
+}
+
+int pose_amd_knn_set_model(pose_amd_ctx *ctx, int npoints, const float *features)
+{
+    if (!ctx || npoints <= 0 || !features) return fail(ctx, POSE_AMD_EINVAL, "knn_set_model: bad argument");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    ctx->knn_points = 0;
+    int rc;
+    if ((rc = upload(ctx, ctx->knn_feat, features, (size_t)npoints * KNN_DIM * 4))) return rc;
+    return knn_build_image(ctx, npoints);
+}
+
+int pose_amd_knn_set_model_views(pose_amd_ctx *ctx, int npoints, const uint32_t *desc_off, const unsigned char *descriptors, float *features_out)
+{
+    if (!ctx || npoints <= 0 || !desc_off || !descriptors || desc_off[0] != 0) return fail(ctx, POSE_AMD_EINVAL, "knn_set_model_views: bad argument");
+    for (int i = 0; i < npoints; ++i)
+        if (desc_off[i + 1] < desc_off[i]) return fail(ctx, POSE_AMD_EINVAL, "knn_set_model_views: offsets must be non-decreasing");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    ctx->knn_points = 0;
+    int rc;
+    const size_t nd = desc_off[npoints];
+    if ((rc = upload(ctx, ctx->knn_in0, desc_off, ((size_t)npoints + 1) * 4)) || (rc = upload(ctx, ctx->knn_in1, descriptors, std::max<size_t>(nd, 1) * KNN_DIM)) ||
+        (rc = ensure(ctx, ctx->knn_feat, (size_t)npoints * KNN_DIM * 4)))
+        return rc;
+    hipLaunchKernelGGL(k_knn_average, dim3(npoints), dim3(KNN_DIM), 0, ctx->stream, npoints, (const unsigned int *)ctx->knn_in0.p,
+                       (const unsigned char *)ctx->knn_in1.p, (float *)ctx->knn_feat.p);
+    HIPCHK(ctx, hipGetLastError());
+    if (features_out && (rc = download(ctx, features_out, ctx->knn_feat.p, (size_t)npoints * KNN_DIM * 4))) return rc;
+    return knn_build_image(ctx, npoints);
+}
+
+int pose_amd_knn_match(pose_amd_ctx *ctx, int nq, const unsigned char *descriptors, float ratio, int *indices, float *dists, unsigned char *good,
+                       int *exhaustive_rows)
+{
+    if (!ctx || nq < 0 || (nq && (!descriptors || !indices || !dists || !good))) return fail(ctx, POSE_AMD_EINVAL, "knn_match: bad argument");
+    if (ctx->knn_points <= 0) return fail(ctx, POSE_AMD_ESTATE, "knn_match: no model set");
+    if (exhaustive_rows) *exhaustive_rows = 0;
+    if (nq == 0) return POSE_AMD_OK;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    int rc;
+    const int npoints = ctx->knn_points, ntiles = cdiv(npoints, 32);
+    // slices of the model: enough blocks for the chip (two per compute unit), at least 64 tiles each
+    const int row_blocks = cdiv(nq, KNN_ROWS);
+    int nslices = std::max(1, std::min(cdiv(ntiles, 64), cdiv(2 * (ctx->cus ? ctx->cus : 256), row_blocks)));
+    if (const char *e = getenv("POSE_AMD_KNN_SLICES")) nslices = std::max(1, std::min(atoi(e), ntiles));
+    const int tps = cdiv(ntiles, nslices);
+    nslices = cdiv(ntiles, tps);
+    const size_t np = (size_t)nq * nslices * KNN_KEEP;
+    if ((rc = upload(ctx, ctx->knn_q, descriptors, (size_t)nq * KNN_DIM)) || (rc = ensure(ctx, ctx->knn_part_s, np * 4)) || (rc = ensure(ctx, ctx->knn_part_i, np * 4)) ||
+        (rc = ensure(ctx, ctx->knn_idx, (size_t)nq * 8)) || (rc = ensure(ctx, ctx->knn_dist, (size_t)nq * 8)) || (rc = ensure(ctx, ctx->knn_good, (size_t)nq)) ||
+        (rc = ensure(ctx, ctx->knn_flag, (size_t)nq * 4 + 4)))
+        return rc;
+    int *nflag_dev = (int *)ctx->knn_flag.p + nq;
+    HIPCHK(ctx, hipMemsetAsync(nflag_dev, 0, 4, ctx->stream));
+    if (ctx->timing) HIPCHK(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
+    hipLaunchKernelGGL(k_knn_scan, dim3(row_blocks, nslices), dim3(256), 0, ctx->stream, nq, (const unsigned char *)ctx->knn_q.p, ntiles, tps,
+                       (const uint4 *)ctx->knn_image.p, (float *)ctx->knn_part_s.p, (int *)ctx->knn_part_i.p);
+    if (ctx->timing) HIPCHK(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
+    hipLaunchKernelGGL(k_knn_finish, dim3(nq), dim3(64), 0, ctx->stream, nq, (const unsigned char *)ctx->knn_q.p, (const float *)ctx->knn_feat.p, npoints, nslices,
+                       (const float *)ctx->knn_part_s.p, (const int *)ctx->knn_part_i.p, (const float *)ctx->knn_fmax.p, ratio, (int *)ctx->knn_idx.p,
+                       (float *)ctx->knn_dist.p, (unsigned char *)ctx->knn_good.p, (int *)ctx->knn_flag.p, nflag_dev);
+    HIPCHK(ctx, hipGetLastError());
+    if (ctx->timing) HIPCHK(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
+    int *host = (int *)ctx->h_words.p;
+    if ((rc = download(ctx, host, nflag_dev, 4)) || (rc = pose_amd_synchronize(ctx))) return rc;
+    const int nflagged = host[0];
+    if (nflagged > 0) {
+        hipLaunchKernelGGL(k_knn_exhaustive, dim3(std::min(nq, 4096)), dim3(256), 0, ctx->stream, nq, (const unsigned char *)ctx->knn_q.p,
+                           (const float *)ctx->knn_feat.p, npoints, (const int *)ctx->knn_flag.p, ratio, (int *)ctx->knn_idx.p, (float *)ctx->knn_dist.p,
+                           (unsigned char *)ctx->knn_good.p);
+        HIPCHK(ctx, hipGetLastError());
+    }
+    if (ctx->timing) HIPCHK(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
+    if (exhaustive_rows) *exhaustive_rows = nflagged;
+    if ((rc = download(ctx, indices, ctx->knn_idx.p, (size_t)nq * 8)) || (rc = download(ctx, dists, ctx->knn_dist.p, (size_t)nq * 8)) ||
+        (rc = download(ctx, good, ctx->knn_good.p, (size_t)nq)) || (rc = pose_amd_synchronize(ctx)))
+        return rc;
+    if (ctx->timing) {
+        for (int i = 0; i < 3; ++i) (void)hipEventElapsedTime(&ctx->knn_last_ms[i], ctx->ev[i], ctx->ev[i + 1]);
+        (void)hipEventElapsedTime(&ctx->knn_last_ms[3], ctx->ev[0], ctx->ev[3]);
+    }
+    return POSE_AMD_OK;
+}
+
+int pose_amd_knn_last_timing(pose_amd_ctx *ctx, float ms[4])
+{
+    if (!ctx || !ms) return POSE_AMD_EINVAL;
+    memcpy(ms, ctx->knn_last_ms, sizeof ctx->knn_last_ms);
+    return POSE_AMD_OK;
 }
 
 // ---- several GPUs from one host process ------------------------------------------------------------
