@@ -563,7 +563,7 @@ def bench_knn(args):
         if not args.no_cpu_baseline:
             sys.path.insert(0, os.path.join(ROOT, "oracle"))
             import knn_oracle as K
-            ns = 64
+            ns = 1536
             t1 = time.perf_counter()
             K.knn2(feat, q[:ns], 0.7)
             dtc = time.perf_counter() - t1

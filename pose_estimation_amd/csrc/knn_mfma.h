@@ -10,7 +10,7 @@
 // bfloat16 part of f: a query descriptor is uint8, exact in bfloat16; a model descriptor is split
 // into f = f_h + f_l + O(2^-17 f), and q f_h, q f_l are exact in float32.  Like the scoring screen of
 // the RANSAC path the matrix result never decides alone:
-//   1. k_knn_scan: a block holds 128 query rows (4 waves x 32) and walks over a slice of the model in
+//   1. k_knn_scan: a block holds 256 query rows (4 waves x 64) and walks over a slice of the model in
 //      tiles of 32 points; every row keeps the KNN_KEEP best scores of the slice.
 //   2. k_knn_finish: the kept points of all slices are re-evaluated exactly (float64 over the float32
 //      descriptors, the arithmetic of the CPU check), the two nearest by (distance, index) are
@@ -37,7 +37,7 @@ namespace pose_amd {
 
 constexpr int KNN_DIM = 128;
 constexpr int KNN_KEEP = 8;                        // scores a row keeps per slice
-constexpr int KNN_ROWS = 128;                      // query rows per block (4 waves x 32)
+constexpr int KNN_ROWS = 256;                      // query rows per block (4 waves x 2 groups of 32)
 constexpr int KNN_TILE_BYTES = 16 * 1024 + 128;    // 32 points: 8 steps x (f_h | f_l) x 1 KB operand images, then 32 |f|^2
 
 // Model image: per tile of 32 points and step kk (16 dimensions) the operand of lane l is the 8
@@ -89,22 +89,28 @@ __global__ __launch_bounds__(128) void k_knn_average(int npoints, const unsigned
     feat[(size_t)p * KNN_DIM + j] = s / (float)(e - b);              // 0 / 0 = NaN for a point without views, as in the reference
 }
 
-// Scan of one slice of the model for 128 query rows.  part_s / part_i: [nq][nslices][KNN_KEEP].
+// Scan of one slice of the model for 256 query rows: 4 waves x 2 groups of 32 rows.  A wave reads a
+// tile's operands from LDS once per step and uses them for both of its groups (the LDS pipe, not
+// the matrix pipe, limited the kernel when every wave had one group).  part_s / part_i:
+// [nq][nslices][KNN_KEEP].
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_knn_scan(int nq, const unsigned char *__restrict__ qdesc, int ntiles,
                                                                                           int tiles_per_slice, const uint4 *__restrict__ image,
                                                                                           float *__restrict__ part_s, int *__restrict__ part_i)
 {
     __shared__ uint4 s_tile[2][KNN_TILE_BYTES / 16];
-    __shared__ float s_dump[4][32][33];                  // a wave's 32 x 32 scores, padded
-    __shared__ float s_tau[4][32];
+    constexpr int QCAP = 256;
+    __shared__ float s_qs[4][QCAP];                      // a wave's queued candidates: score ...
+    __shared__ unsigned int s_qe[4][QCAP];               // ... and (row of the wave << 16 | column)
+    __shared__ float s_tau[4][64];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int row0 = blockIdx.x * KNN_ROWS + wave * 32;
+    const int row0 = blockIdx.x * KNN_ROWS + wave * 64;
     const int slice = blockIdx.y, nslices = gridDim.y;
     const int t_begin = slice * tiles_per_slice, t_end = min(ntiles, t_begin + tiles_per_slice);
-    // the wave's query operands: lane l holds q[row0 + l % 32][16 kk + 8 (l / 32) + 0..7] of every step
-    bf16x8 qa[8];
-    {
-        const int r = row0 + (lane & 31);
+    // the wave's query operands: lane l holds q[row0 + 32 g + l % 32][16 kk + 8 (l / 32) + 0..7] of every step
+    bf16x8 qa[2][8];
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        const int r = row0 + 32 * g + (lane & 31);
 #pragma unroll
         for (int kk = 0; kk < 8; ++kk) {
             unsigned w[4] = {0, 0, 0, 0};
@@ -117,82 +123,130 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             }
             typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
             const u32x4 v = {w[0], w[1], w[2], w[3]};
-            qa[kk] = __builtin_bit_cast(bf16x8, v);
+            qa[g][kk] = __builtin_bit_cast(bf16x8, v);
         }
     }
-    // rows of the wave's result that the lane sees: i(r) = 8 (r / 4) + 4 (lane / 32) + r % 4
-    float tau[16];
+    // rows of a group's result that the lane sees: i(r) = 8 (r / 4) + 4 (lane / 32) + r % 4
+    float tau[2][16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) tau[r] = __builtin_inff();
-    // lane l < 32 owns row l's kept scores, ascending
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) tau[g][r] = __builtin_inff();
+    // lane l owns row l of the wave's 64 (group l / 32): its kept scores, ascending
     float best_s[KNN_KEEP];
     int best_i[KNN_KEEP];
 #pragma unroll
     for (int k = 0; k < KNN_KEEP; ++k) { best_s[k] = __builtin_inff(); best_i[k] = -1; }
 
-    // a tile is fetched into registers before the products of the previous one and stored to LDS after them
+    // Tiles travel global memory -> registers -> LDS.  A tile is fetched KNN_AHEAD iterations before it
+    // is used (an iteration is shorter than the latency of the fetch): register set k holds the tiles t
+    // with (t - t_begin) % KNN_AHEAD == k; at the end of iteration t the set of tile t + 1 is stored to
+    // the LDS buffer that tile t - 1 used and refilled with tile t + 1 + KNN_AHEAD.
     constexpr int NPRE = (KNN_TILE_BYTES / 16 + 255) / 256;
-    uint4 pre[NPRE];
-    auto fetch = [&](int tile) {
+    constexpr int AHEAD = 2;
+    uint4 pre[AHEAD][NPRE];
+    auto fetch = [&](uint4 (&set)[NPRE], int tile) {
+        if (tile >= t_end) return;                       // block-uniform
         const uint4 *src = image + (size_t)tile * (KNN_TILE_BYTES / 16);
 #pragma unroll
-        for (int k = 0; k < NPRE; ++k) { const int i = tid + 256 * k; pre[k] = i < KNN_TILE_BYTES / 16 ? src[i] : make_uint4(0u, 0u, 0u, 0u); }
+        for (int k = 0; k < NPRE; ++k) { const int i = tid + 256 * k; set[k] = i < KNN_TILE_BYTES / 16 ? src[i] : make_uint4(0u, 0u, 0u, 0u); }
     };
-    auto store = [&](int buf) {
+    auto store = [&](const uint4 (&set)[NPRE], int buf) {
 #pragma unroll
-        for (int k = 0; k < NPRE; ++k) { const int i = tid + 256 * k; if (i < KNN_TILE_BYTES / 16) s_tile[buf][i] = pre[k]; }
+        for (int k = 0; k < NPRE; ++k) { const int i = tid + 256 * k; if (i < KNN_TILE_BYTES / 16) s_tile[buf][i] = set[k]; }
     };
-    if (t_begin < t_end) { fetch(t_begin); store(0); }
+    fetch(pre[0], t_begin);
+    if (t_begin < t_end) store(pre[0], 0);
+#pragma unroll
+    for (int k = 1; k <= AHEAD; ++k) fetch(pre[k % AHEAD], t_begin + k);
     __syncthreads();
-    for (int t = t_begin; t < t_end; ++t) {
+    for (int t0 = t_begin; t0 < t_end; t0 += AHEAD) {
+#pragma unroll
+      for (int u = 0; u < AHEAD; ++u) {
+        const int t = t0 + u;
+        if (t >= t_end) break;                           // block-uniform
         const int buf = (t - t_begin) & 1;
-        if (t + 1 < t_end) fetch(t + 1);
         const uint4 *tile = s_tile[buf];
-        f32x16 acc = {};
+        // four accumulator chains: two groups of rows x the two parts of f
+        f32x16 acc[2][2] = {};
 #pragma unroll
         for (int kk = 0; kk < 8; ++kk) {
             const bf16x8 bh = __builtin_bit_cast(bf16x8, tile[kk * 128 + lane]);
             const bf16x8 bl = __builtin_bit_cast(bf16x8, tile[kk * 128 + 64 + lane]);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[kk], bh, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[kk], bl, acc, 0, 0, 0);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[0][kk], bh, acc[0][0], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[1][kk], bh, acc[1][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[0][kk], bl, acc[0][1], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[1][kk], bl, acc[1][1], 0, 0, 0);
         }
         const float fn = reinterpret_cast<const float *>(tile + 1024)[lane & 31];
-        float s[16];
-        bool any = false;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { s[r] = fmaf(-2.0f, acc[r], fn); any = any || s[r] < tau[r]; }
-        if (__ballot(any)) {
-            // some row of the wave has a new candidate: all 32 x 32 scores go through LDS to the rows' owners
-#pragma unroll
-            for (int r = 0; r < 16; ++r) s_dump[wave][8 * (r >> 2) + 4 * (lane >> 5) + (r & 3)][lane & 31] = s[r];
+        int qn = 0;                                      // wave-uniform number of queued candidates
+        bool drained = false;
+        // hands the queued candidates to the lanes that own their rows
+        auto drain = [&]() {
             __builtin_amdgcn_wave_barrier();
-            if (lane < 32) {
-                for (int j = 0; j < 32; ++j) {
-                    const float v = s_dump[wave][lane][j];
-                    if (v < best_s[KNN_KEEP - 1]) {
-                        // insert (v, point); equal scores keep the earlier point in front
-                        float cs = v;
-                        int ci = t * 32 + j;
+            for (int e = 0; e < qn; ++e) {
+                const unsigned code = s_qe[wave][e];
+                if ((int)(code >> 16) == lane) {
+                    // insert (score, point); equal scores keep the earlier point in front
+                    float cs = s_qs[wave][e];
+                    int ci = t * 32 + (int)(code & 0xffffu);
 #pragma unroll
-                        for (int k = 0; k < KNN_KEEP; ++k) {
-                            const bool sw = cs < best_s[k];
-                            const float ts = best_s[k];
-                            const int ti = best_i[k];
-                            best_s[k] = sw ? cs : ts; best_i[k] = sw ? ci : ti;
-                            cs = sw ? ts : cs; ci = sw ? ti : ci;
-                        }
+                    for (int k = 0; k < KNN_KEEP; ++k) {
+                        const bool sw = cs < best_s[k];
+                        const float ts = best_s[k];
+                        const int ti = best_i[k];
+                        best_s[k] = sw ? cs : ts; best_i[k] = sw ? ci : ti;
+                        cs = sw ? ts : cs; ci = sw ? ti : ci;
                     }
                 }
-                s_tau[wave][lane] = best_s[KNN_KEEP - 1];
             }
             __builtin_amdgcn_wave_barrier();
+            qn = 0;
+            drained = true;
+        };
 #pragma unroll
-            for (int r = 0; r < 16; ++r) tau[r] = s_tau[wave][8 * (r >> 2) + 4 * (lane >> 5) + (r & 3)];
+        for (int g = 0; g < 2; ++g) {
+            float s[16];
+            unsigned long long open[16], any_open = 0;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                s[r] = fmaf(-2.0f, acc[g][0][r] + acc[g][1][r], fn);
+                open[r] = __ballot(s[r] < tau[g][r]);
+                any_open |= open[r];
+            }
+            if (any_open) {
+                // Some row of the group has a candidate (after the first tiles: in about every other
+                // tile, one or two of the 1 024 scores).  The candidates go through a queue in LDS to
+                // the lanes that own their rows; per row they arrive in the order of their points.
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const unsigned long long m = open[r];
+                    if (!m) continue;
+                    if ((m >> lane) & 1ull) {
+                        const unsigned pos = (unsigned)qn + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+                        s_qs[wave][pos] = s[r];
+                        s_qe[wave][pos] = ((unsigned)(32 * g + 8 * (r >> 2) + 4 * (lane >> 5) + (r & 3)) << 16) | (unsigned)(lane & 31);
+                    }
+                    qn += __popcll(m);
+                    if (qn > QCAP - 64) drain();                 // only in a slice's first tiles, while the thresholds are still +inf
+                }
+            }
         }
-        if (t + 1 < t_end) store(buf ^ 1);               // the other buffer was last read before the previous barrier
+        if (qn) drain();
+        if (drained) {
+            s_tau[wave][lane] = best_s[KNN_KEEP - 1];
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int g = 0; g < 2; ++g)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) tau[g][r] = s_tau[wave][32 * g + 8 * (r >> 2) + 4 * (lane >> 5) + (r & 3)];
+        }
+        if (t + 1 < t_end) store(pre[(u + 1) % AHEAD], buf ^ 1);   // the other buffer was last read before the previous barrier
+        fetch(pre[(u + 1) % AHEAD], t + 1 + AHEAD);
         __syncthreads();                                 // the next tile is staged, this one is no longer read
+      }
     }
-    if (lane < 32 && row0 + lane < nq) {
+    if (row0 + lane < nq) {
         const size_t o = ((size_t)(row0 + lane) * nslices + slice) * KNN_KEEP;
 #pragma unroll
         for (int k = 0; k < KNN_KEEP; ++k) { part_s[o + k] = best_s[k]; part_i[o + k] = best_i[k]; }
