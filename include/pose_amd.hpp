@@ -138,7 +138,51 @@ struct SiftMatch {
 };
 struct SIFT_keypoint { float x = 0, y = 0, scale = 0, orientation = 0; };
 struct point3D { float x = 0, y = 0, z = 0; };
-struct feature_3D_info { point3D point; };
+// parse_bundler.hpp:125-175: a 3-D point and the SIFT descriptors of its views (128 bytes per view)
+struct feature_3D_info {
+    point3D point;
+    std::vector<unsigned char> descriptors;
+};
+
+// The matching step of QueryProcessorBasic (query_processor_basic.cpp:22-53 and :60-96): one float
+// descriptor per 3-D point -- the mean of the descriptors of its views -- and, per query
+// descriptor, the two nearest of them by squared L2 distance with Lowe's ratio test.  The search is
+// exact where the reference's FLANN kd-tree search is approximate.
+class DescriptorMatcher {
+public:
+    explicit DescriptorMatcher(const std::vector<feature_3D_info> &sifts, Device *dev = nullptr) : dev_(dev ? dev : &Device::current())
+    {
+        std::vector<uint32_t> off(sifts.size() + 1, 0);
+        for (size_t i = 0; i < sifts.size(); ++i) off[i + 1] = off[i] + (uint32_t)(sifts[i].descriptors.size() / 128);
+        std::vector<unsigned char> all((size_t)off.back() * 128 + 1);
+        for (size_t i = 0; i < sifts.size(); ++i)
+            std::copy(sifts[i].descriptors.begin(), sifts[i].descriptors.begin() + (size_t)(off[i + 1] - off[i]) * 128, all.begin() + (size_t)off[i] * 128);
+        dev_->check(pose_amd_knn_set_model_views(dev_->ctx(), (int)sifts.size(), off.data(), all.data(), nullptr), "knn_set_model_views");
+    }
+    // descriptors: 128 bytes per query keypoint (Query::sift_descriptors()); returns good_matches
+    // (lindex = keypoint, mindex = nearest 3-D point, distance = squared L2 distance to it)
+    std::vector<SiftMatch> Match(const std::vector<unsigned char *> &descriptors, float ratio = 0.7f) const
+    {
+        const size_t n = descriptors.size();
+        std::vector<unsigned char> q(n * 128 + 1);
+        for (size_t i = 0; i < n; ++i) std::copy(descriptors[i], descriptors[i] + 128, q.begin() + i * 128);
+        std::vector<int> idx(2 * n + 1);
+        std::vector<float> dist(2 * n + 1);
+        std::vector<unsigned char> good(n + 1);
+        dev_->check(pose_amd_knn_match(dev_->ctx(), (int)n, q.data(), ratio, idx.data(), dist.data(), good.data(), nullptr), "knn_match");
+        std::vector<SiftMatch> out;
+        for (size_t i = 0; i < n; ++i) {
+            if (!good[i]) continue;
+            SiftMatch m;
+            m.lindex = (unsigned)i; m.mindex = (unsigned)idx[2 * i]; m.distance = dist[2 * i];
+            out.push_back(m);
+        }
+        return out;
+    }
+
+private:
+    Device *dev_;
+};
 
 // The pose-related part of query_loader.hpp:30-75.
 class Query {

@@ -94,6 +94,31 @@ public:
         }
         return !in.fail();
     }
+    // parse_bundler.cpp:225-290: the descriptors of every point's views, taken from the Lowe .key file
+    // of the view's camera (key_files[camera]; the view list names the keypoint inside that file).
+    // Fills feature_3D_info::descriptors, 128 bytes per view in view-list order.
+    bool load_descriptors(const std::vector<std::string> &key_files)
+    {
+        if (key_files.size() < cameras_.size()) return false;
+        for (size_t i = 0; i < points_.size(); ++i) points_[i].descriptors.assign(views_[i].size() * 128, 0);
+        for (size_t c = 0; c < cameras_.size(); ++c) {
+            bool needed = false;
+            for (size_t i = 0; i < points_.size() && !needed; ++i)
+                for (const bundler_view &v : views_[i]) needed = needed || v.camera == c;
+            if (!needed) continue;
+            SIFT_loader keys;
+            if (!keys.load_Lowe_features(key_files[c].c_str())) return false;
+            const std::vector<unsigned char> &d = keys.get_descriptors();
+            for (size_t i = 0; i < points_.size(); ++i)
+                for (size_t k = 0; k < views_[i].size(); ++k) {
+                    const bundler_view &v = views_[i][k];
+                    if (v.camera != c) continue;
+                    if ((size_t)v.key >= keys.get_nb_features()) return false;
+                    std::copy(d.begin() + (size_t)v.key * 128, d.begin() + ((size_t)v.key + 1) * 128, points_[i].descriptors.begin() + k * 128);
+                }
+        }
+        return true;
+    }
     std::vector<bundler_camera> &get_cameras() { return cameras_; }
     std::vector<feature_3D_info> &get_feature_infos() { return points_; }
     // the cameras that see point i: what SiftMatch::camset holds (advanced.cpp:272-285)

@@ -350,6 +350,56 @@ static void test_benchmark()
     CHECK(src.queries[0].camera_position()(0, 0) == 0.0);           // Benchmark works on copies, like GetQuery(i, false)
 }
 
+// query_processor_basic.cpp:22-96: averaged descriptors, two nearest, ratio test -- against plain loops
+static void test_matching()
+{
+    std::mt19937 rng(5);
+    std::uniform_int_distribution<int> byte(0, 90), views(1, 4), jitter(-4, 4);
+    std::vector<feature_3D_info> sifts(300);
+    for (auto &s : sifts) {
+        std::vector<int> proto(128);
+        for (int &v : proto) v = byte(rng);
+        const int nv = views(rng);
+        for (int k = 0; k < nv; ++k)
+            for (int j = 0; j < 128; ++j) s.descriptors.push_back((unsigned char)std::max(0, std::min(255, proto[j] + jitter(rng))));
+    }
+    sifts[77].descriptors = sifts[12].descriptors;                       // an exact tie: the lower index comes first
+    std::vector<std::vector<unsigned char>> store(60, std::vector<unsigned char>(128));
+    std::vector<unsigned char *> desc;
+    for (size_t i = 0; i < store.size(); ++i) {
+        for (int j = 0; j < 128; ++j)
+            store[i][j] = i % 2 ? (unsigned char)byte(rng) : (unsigned char)std::max(0, std::min(255, (int)sifts[(i * 5) % 300].descriptors[j] + jitter(rng)));
+        desc.push_back(store[i].data());
+    }
+    DescriptorMatcher matcher(sifts);
+    std::vector<SiftMatch> good = matcher.Match(desc, 0.7f);
+    // the definition, in the reference's arithmetic for the averages and double sums for the distances
+    std::vector<std::vector<float>> feat(sifts.size(), std::vector<float>(128, 0.f));
+    for (size_t i = 0; i < sifts.size(); ++i) {
+        const size_t nv = sifts[i].descriptors.size() / 128;
+        for (size_t k = 0; k < nv; ++k) for (int j = 0; j < 128; ++j) feat[i][j] += (float)sifts[i].descriptors[j + 128 * k];
+        for (int j = 0; j < 128; ++j) feat[i][j] /= (float)nv;
+    }
+    size_t g = 0, expected_good = 0;
+    for (size_t i = 0; i < desc.size(); ++i) {
+        double d1 = 1e300, d2 = 1e300;
+        size_t i1 = 0;
+        for (size_t p = 0; p < feat.size(); ++p) {
+            double d = 0;
+            for (int j = 0; j < 128; ++j) { const double t = (double)desc[i][j] - (double)feat[p][j]; d += t * t; }
+            if (d < d1) { d2 = d1; d1 = d; i1 = p; } else if (d < d2) d2 = d;
+        }
+        const bool is_good = (float)d1 / (float)d2 < 0.7f;
+        expected_good += is_good;
+        if (is_good) {
+            CHECK(g < good.size() && good[g].lindex == i && good[g].mindex == i1);
+            if (g < good.size()) CHECK(std::fabs(good[g].distance - (float)d1) <= 1e-6f * (float)d1);
+            ++g;
+        }
+    }
+    CHECK(g == good.size() && expected_good >= 20 && expected_good <= 40);
+}
+
 int main()
 {
     try {
@@ -360,6 +410,7 @@ int main()
         test_project();
         test_backmatching();
         test_benchmark();
+        test_matching();
     } catch (const std::exception &e) {
         std::printf("EXCEPTION %s\n", e.what());
         return 2;

@@ -55,6 +55,22 @@ int main(int argc, char **argv)
     CHECK(pb.get_cameras()[1].rotation(0, 1) == -1.0 && pb.get_cameras()[1].rotation(1, 0) == 1.0);
     CHECK(pb.get_feature_infos()[0].point.z == -3.5f && pb.get_feature_infos()[1].point.x == -1.0f);
     CHECK(pb.camset(0).size() == 2 && pb.camset(0).count(1) == 1 && pb.camset(1).size() == 1);
+    {   // descriptors of the views: camera 0 sees point 0 as its keypoint 17, camera 1 sees point 0 as 4 and point 1 as 9
+        for (int c = 0; c < 2; ++c) {
+            std::ofstream f(dir + (c ? "/c1.key" : "/c0.key"));
+            f << "20 128\n";
+            for (int k = 0; k < 20; ++k) {
+                f << "1 2 3 4\n";
+                for (int j = 0; j < 128; ++j) f << " " << ((j + 10 * k + 100 * c) % 256);
+                f << "\n";
+            }
+        }
+        CHECK(pb.load_descriptors({dir + "/c0.key", dir + "/c1.key"}));
+        const std::vector<unsigned char> &d0 = pb.get_feature_infos()[0].descriptors, &d1 = pb.get_feature_infos()[1].descriptors;
+        CHECK(d0.size() == 256 && d1.size() == 128);
+        CHECK(d0[0] == (0 + 170) % 256 && d0[128 + 5] == (5 + 40 + 100) % 256 && d1[127] == (127 + 90 + 100) % 256);
+        CHECK(!pb.load_descriptors({dir + "/c0.key"}));                        // a key file per camera
+    }
     // query 0 = the first "query/" line = camera 2: R = [0 -1 0; 1 0 0; 0 0 1], t = (1, 2, 3)
     Query g = LoadGoldenQuery(pb, 0, dir + "/");
     CHECK(g.focal_length() == 800.0);
