@@ -604,27 +604,35 @@ def roofline_shared_launches(resident, queries, res, sample_mode, select, args):
         if st[0]:
             pairs += computed * (st[1] / st[0]) * (st[2] / st[3])
     mean_pix = pix / max(len(queries), 1)
-    work = {"k_seg_score_screen": (t["score_ms"], pairs * SCORE_FLOP_PER_PAIR),
+    from pose_estimation_amd import SAMPLE_BASIC
+    # the library's rule: matrix-core screen for the basic sampler's (mostly junk) poses, packed float32 screen otherwise
+    mfma_used = sample_mode == SAMPLE_BASIC and os.environ.get("POSE_AMD_SEG_SCORE") != "packed" and os.environ.get("POSE_AMD_SCORE") not in ("packed", "fp64")
+    score_kernel = "k_seg_score_mfma" if mfma_used else "k_seg_score_screen"
+    work = {score_kernel: (t["score_ms"], pairs * SCORE_FLOP_PER_PAIR),
             "k_seg_p4pf_elim": (t["elim_ms"], t["p4pf_steps_computed"] * ELIM_FLOP_PER_HYP),
             "k_seg_p4pf_finish": (t["finish_ms"], t["p4pf_steps_computed"] * FINISH_FLOP_PER_HYP),
             "k_seg_solve_p3p": (t["p3p_ms"], t["p3p_steps_computed"] * P3P_FLOP_PER_HYP)}
     # coverage areas: no floating-point work; a pose's bitmap (one bit per pixel) is cleared and counted in LDS
     cov_bytes = t["poses_painted"] * mean_pix / 8 * 2
     times = dict((k, v[0]) for k, v in work.items())
-    times["k_seg_coverage"] = t["coverage_ms"]
+    times["k_seg_cover_pose"] = t["coverage_ms"]
     dom = max(times, key=lambda k: times[k])
     ms = {k: round(v, 3) for k, v in t.items() if k.endswith("_ms")}
-    if dom == "k_seg_coverage":
+    if dom == "k_seg_cover_pose":
         ach = cov_bytes / (t["coverage_ms"] * 1e-3) / 1e9
         rl = {"kernel": dom, "bound": "lds", "achieved": round(ach, 1), "peak": round(LDS_PEAK_GBS, 1), "unit": "GB/s", "frac": round(ach / LDS_PEAK_GBS, 4),
               "traffic": None, "algorithmic": "2 x width x height / 8 bytes of LDS per pose painted (clear the bitmap, count it)"}
+    elif dom == "k_seg_score_mfma":
+        mf = pairs * SCREEN_MFMA_FLOP_PER_PAIR / (t["score_ms"] * 1e-3) / 1e12
+        rl = {"kernel": dom, "bound": "mfma", "achieved": round(mf, 1), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(mf / BF16_MFMA_PEAK_TFLOPS, 4),
+              "traffic": None, "pairs_per_s": round(pairs / (t["score_ms"] * 1e-3), 1)}
     else:
         tf = work[dom][1] / (work[dom][0] * 1e-3) / 1e12 if work[dom][0] > 0 else 0.0
         rl = {"kernel": dom, "bound": "valu_fp64", "achieved": round(tf, 3), "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
               "frac": round(tf / FP64_VECTOR_PEAK_TFLOPS, 4), "traffic": None}
     rl.update({"launches": t["launches"], "kernel_ms_per_step": ms,
                "kernel_tflops": {k: round(f / (m * 1e-3) / 1e12, 3) for k, (m, f) in work.items() if m > 0},
-               "k_seg_coverage_lds_gbs": round(cov_bytes / (t["coverage_ms"] * 1e-3) / 1e9, 1) if t["coverage_ms"] > 0 else None,
+               "k_seg_cover_pose_lds_gbs": round(cov_bytes / (t["coverage_ms"] * 1e-3) / 1e9, 1) if t["coverage_ms"] > 0 else None,
                "steps_computed": t["p3p_steps_computed"] + t["p4pf_steps_computed"], "poses_painted": t["poses_painted"],
                "pairs_scored": round(pairs, 1),
                "note": "HIP events after every launch of one run of the resident list (outside the timed region); kernel_ms_per_step is that run's "

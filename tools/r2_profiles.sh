@@ -20,5 +20,6 @@ trace dub_adv --workload dubrovnik --advanced --steps 3 --warmup 1 --no-cpu-base
 trace dub_fixed --workload dubrovnik --steps 3 --warmup 1 --no-cpu-baseline || exit 1
 trace p3p --known-focal --matches 2000 --inlier-frac 0.3 --no-cpu-baseline || exit 1
 trace large --matches 100000 --inlier-frac 0.01 --hyps 262144 --steps 5 --warmup 1 --no-cpu-baseline || exit 1
+trace knn --workload knn --steps 5 --warmup 1 --no-cpu-baseline || exit 1
 tools/collect_pmc.sh "$OUT/pmc" || exit 1
 echo done
