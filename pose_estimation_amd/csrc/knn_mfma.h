@@ -93,12 +93,15 @@ __global__ __launch_bounds__(128) void k_knn_average(int npoints, const unsigned
 // tile's operands from LDS once per step and uses them for both of its groups (the LDS pipe, not
 // the matrix pipe, limited the kernel when every wave had one group).  part_s / part_i:
 // [nq][nslices][KNN_KEEP].
+// (Starting every slice from the thresholds of a scan of a small sample of the model, instead of
+// +inf, cuts the queued candidates by two thirds and measured no faster: the kernel's time is the
+// barrier per tile, not the candidates.)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_knn_scan(int nq, const unsigned char *__restrict__ qdesc, int ntiles,
                                                                                           int tiles_per_slice, const uint4 *__restrict__ image,
                                                                                           float *__restrict__ part_s, int *__restrict__ part_i)
 {
     __shared__ uint4 s_tile[2][KNN_TILE_BYTES / 16];
-    constexpr int QCAP = 256;
+    constexpr int QCAP = 1024;                           // all scores of one group of rows: a tile's first-ever candidates
     __shared__ float s_qs[4][QCAP];                      // a wave's queued candidates: score ...
     __shared__ unsigned int s_qe[4][QCAP];               // ... and (row of the wave << 16 | column)
     __shared__ float s_tau[4][64];
@@ -143,7 +146,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // with (t - t_begin) % KNN_AHEAD == k; at the end of iteration t the set of tile t + 1 is stored to
     // the LDS buffer that tile t - 1 used and refilled with tile t + 1 + KNN_AHEAD.
     constexpr int NPRE = (KNN_TILE_BYTES / 16 + 255) / 256;
-    constexpr int AHEAD = 2;
+    constexpr int AHEAD = 1;                             // (deeper prefetch measured 3 % faster and doubles the code of the loop)
     uint4 pre[AHEAD][NPRE];
     auto fetch = [&](uint4 (&set)[NPRE], int tile) {
         if (tile >= t_end) return;                       // block-uniform
@@ -169,14 +172,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const uint4 *tile = s_tile[buf];
         // four accumulator chains: two groups of rows x the two parts of f
         f32x16 acc[2][2] = {};
+        // the operands of step kk + 1 are read from LDS while the four products of step kk run
+        bf16x8 bh = __builtin_bit_cast(bf16x8, tile[lane]), bl = __builtin_bit_cast(bf16x8, tile[64 + lane]);
 #pragma unroll
         for (int kk = 0; kk < 8; ++kk) {
-            const bf16x8 bh = __builtin_bit_cast(bf16x8, tile[kk * 128 + lane]);
-            const bf16x8 bl = __builtin_bit_cast(bf16x8, tile[kk * 128 + 64 + lane]);
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[0][kk], bh, acc[0][0], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[1][kk], bh, acc[1][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[0][kk], bl, acc[0][1], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[1][kk], bl, acc[1][1], 0, 0, 0);
+            const bf16x8 ch = bh, cl = bl;
+            if (kk < 7) {
+                bh = __builtin_bit_cast(bf16x8, tile[(kk + 1) * 128 + lane]);
+                bl = __builtin_bit_cast(bf16x8, tile[(kk + 1) * 128 + 64 + lane]);
+            }
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[0][kk], ch, acc[0][0], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[1][kk], ch, acc[1][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[0][kk], cl, acc[0][1], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[1][kk], cl, acc[1][1], 0, 0, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);      // two LDS reads ...
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);      // ... then the four matrix instructions
         }
         const float fn = reinterpret_cast<const float *>(tile + 1024)[lane & 31];
         int qn = 0;                                      // wave-uniform number of queued candidates
@@ -228,11 +238,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                         s_qe[wave][pos] = ((unsigned)(32 * g + 8 * (r >> 2) + 4 * (lane >> 5) + (r & 3)) << 16) | (unsigned)(lane & 31);
                     }
                     qn += __popcll(m);
-                    if (qn > QCAP - 64) drain();                 // only in a slice's first tiles, while the thresholds are still +inf
                 }
+                drain();                                     // once per group: the code of the insertion is not replicated per result register
             }
         }
-        if (qn) drain();
         if (drained) {
             s_tau[wave][lane] = best_s[KNN_KEEP - 1];
             __builtin_amdgcn_wave_barrier();
