@@ -29,6 +29,11 @@ struct seg_query {
     int separable;               // the row-union coverage kernel fits this image
     int bm_words;                // advanced sampler: words of the camera bitmap, 0 = merge lists
     int cv_rows;                 // output rows per pass of k_seg_cover_pose, 0: the query's areas come from k_seg_coverage
+    // k_seg_cover_pose reads the correspondences in the order of their keypoint rows (copies sorted by
+    // rint(ky), made when the list is created): the ones a pass can paint are then a range of positions,
+    // pass p: [cv_lo[p], cv_hi[p]) (at most CVP_PASSES passes)
+    const float *skx, *sky, *sX, *sY, *sZ;
+    unsigned short cv_lo[16], cv_hi[16];
     const uint4 *feat;           // feature image of the matrix-core screen (score_mfma.h), null: not built
     query_centre qc;             // centre of the 3-D points and largest distance from it
 };
@@ -272,7 +277,9 @@ __global__ __launch_bounds__(256) void k_seg_coverage(seg_launch L, seg_cov C, i
 // 256 * CVP_KM correspondences on images whose bitmap rows are short enough).  The block first
 // decides the pose's inliers (the float64 test of the scoring kernels; every thread keeps the bits
 // of its CVP_KM correspondences, whose integer keypoint positions it holds packed in registers for
-// all poses of the block), then walks over the image in passes of cv_rows output rows: clear the
+// all poses of the block; the correspondences are taken in the order of their keypoint rows, so
+// that the ones near a pass are a range of slots and the paint loop skips the others without
+// looking at them), then walks over the image in passes of cv_rows output rows: clear the
 // pass's rows in LDS, paint every inlier's column interval into the row of its own y, form the
 // unions of aligned groups of eight rows, form every output row as the union of the 2h painted
 // rows above it and count (the scheme of coverage_band).  Differences that make it cheaper per
@@ -288,6 +295,7 @@ __global__ __launch_bounds__(256) void k_seg_coverage(seg_launch L, seg_cov C, i
 constexpr int CVP_THREADS = CVP_T;       // threads per block
 constexpr int CVP_KM = 6144 / CVP_THREADS;   // correspondences per thread
 constexpr int CVP_BIAS = 16384;          // keypoint coordinates are stored as 16-bit values with this bias
+constexpr int CVP_PASSES = 16;           // passes a query may need (more: the query's areas come from k_seg_coverage)
 
 __global__ __launch_bounds__(CVP_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_seg_cover_pose(seg_launch L, seg_cov C, int which, const double *__restrict__ proj, double eps)
 {
@@ -322,7 +330,7 @@ __global__ __launch_bounds__(CVP_THREADS) __attribute__((amdgpu_waves_per_eu(4, 
         const int i = tid + k * CVP_THREADS;
         unsigned v = 0xFFFFFFFFu;
         if (i < q.n) {
-            const int x = (int)rintf(q.kx[i]), y = (int)rintf(q.ky[i]);
+            const int x = (int)rintf(sq.skx[i]), y = (int)rintf(sq.sky[i]);
             const int sx = max(0, min(x - h, q.width - 1)), sy = max(0, min(y - h, q.height - 1));
             const int ex = max(0, min(x + h, q.width - 1)), ey = max(0, min(y + h, q.height - 1));
             if (sy < ey && sx < ex) v = (unsigned)(x + CVP_BIAS) | ((unsigned)(y + CVP_BIAS) << 16);   // then -h < x < width + h, likewise y
@@ -342,8 +350,8 @@ __global__ __launch_bounds__(CVP_THREADS) __attribute__((amdgpu_waves_per_eu(4, 
         for (int k = 0; k < CVP_KM; ++k) {
             if (k * CVP_THREADS >= q.n) break;                       // block-uniform
             const int i = min(tid + k * CVP_THREADS, q.n - 1);       // loads without a branch in front of them
-            const float kxf = q.kx[i], kyf = q.ky[i];
-            const double X = q.X[i], Y = q.Y[i], Z = q.Z[i];
+            const float kxf = sq.skx[i], kyf = sq.sky[i];
+            const double X = sq.sX[i], Y = sq.sY[i], Z = sq.sZ[i];
             const double u = -((double)kxf - hw), v = -((double)kyf - hh);
             const double px = fma(P[0], X, fma(P[1], Y, fma(P[2], Z, P[3])));
             const double py = fma(P[4], X, fma(P[5], Y, fma(P[6], Z, P[7])));
@@ -353,8 +361,10 @@ __global__ __launch_bounds__(CVP_THREADS) __attribute__((amdgpu_waves_per_eu(4, 
             if (rxy[k] != 0xFFFFFFFFu && fma(ry, ry, rx * rx) < te * te) inl |= 1u << k;     // rxy is ~0 beyond n as well
         }
         unsigned long long area = 0;
-        for (int row0 = (int)blockIdx.y * RB; row0 < q.height; row0 += ny * RB) {
+        for (int row0 = (int)blockIdx.y * RB, pass = (int)blockIdx.y; row0 < q.height; row0 += ny * RB, pass += ny) {
             const int row1 = min(q.height, row0 + RB);
+            // the slots k of the thread's correspondences (position tid + CVP_THREADS k in row order) that can lie near this pass
+            const int k_lo = sq.cv_lo[pass] / CVP_THREADS, k_hi = (sq.cv_hi[pass] + CVP_THREADS - 1) / CVP_THREADS;
             const int nh = (row1 - row0) + 2 * h - 1, ng = (nh + 7) >> 3;
             const int y_base = row0 - h + 1;
             __syncthreads();                                 // the previous pass (or pose) is done with the rows
@@ -368,6 +378,7 @@ __global__ __launch_bounds__(CVP_THREADS) __attribute__((amdgpu_waves_per_eu(4, 
             bool any = false;
 #pragma unroll
             for (int k = 0; k < CVP_KM; ++k) {
+                if (k < k_lo || k >= k_hi) continue;             // block-uniform
                 if (!((inl >> k) & 1u)) continue;
                 const int x = (int)(rxy[k] & 0xFFFFu) - CVP_BIAS, y = (int)(rxy[k] >> 16) - CVP_BIAS;
                 const int yy = y - y_base;

@@ -491,7 +491,9 @@ __device__ __forceinline__ void p4pf_finish_block(const query_dev &q, uint32_t h
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) nmax = max(nmax, __shfl_xor(nmax, o));
     int qn = 0;                                          // wave-uniform queue length
-    for (int r = 0; r < nmax; ++r) {
+    // One more pass than there are root indices: the last one queues nothing and recovers what is
+    // left, so that the (large) code of the recovery exists once in the kernel.
+    for (int r = 0; r <= nmax; ++r) {
         const bool has = r < n;
         const unsigned long long m = __ballot(has);
         if (has) {
@@ -501,19 +503,19 @@ __device__ __forceinline__ void p4pf_finish_block(const query_dev &q, uint32_t h
         }
         qn += __popcll(m);
         __builtin_amdgcn_wave_barrier();
-        if (qn >= 64) {
-            recover(64);
+        if (qn >= 64 || (r == nmax && qn > 0)) {
+            const int take = min(qn, 64);
+            recover(take);
             __builtin_amdgcn_wave_barrier();
-            const bool mv = lane < qn - 64;
+            const bool mv = lane < qn - take;
             p4pf_root keep = s_root[mv ? 64 + lane : 0];
             const unsigned short km = s_meta[mv ? 64 + lane : 0];
             __builtin_amdgcn_wave_barrier();
             if (mv) { s_root[lane] = keep; s_meta[lane] = km; }
-            qn -= 64;
+            qn -= take;
             __builtin_amdgcn_wave_barrier();
         }
     }
-    recover(qn);
 }
 
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_p4pf_finish(query_dev q, uint32_t hyp_count, const uint32_t *__restrict__ samples, const double *__restrict__ m2d_in,

@@ -96,9 +96,14 @@ struct pose_amd_ctx {
     int knn_points = 0;
     float knn_last_ms[4] = {0, 0, 0, 0};
     // segmented batch (many queries per launch): packed queries, descriptor table, per-hypothesis arrays, selection scratch
-    dev_buf sg_vlist, sg_vcount, sg_samples, sg_sstatus, sg_arows, sg_pstatus, sg_proj, sg_pose, sg_projf, sg_nsol, sg_counts, sg_n,
-        sg_list1, sg_area1, sg_bands1, sg_list2, sg_bands2, sg_mslot, sg_marea, sg_mkeep, sg_allsums;
+    // one set per solver: the P3P and the P4Pf queries of a round run on two streams
+    struct seg_scratch {
+        dev_buf vlist, vcount, samples, sstatus, arows, pstatus, proj, pose, projf, nsol, counts, n, list1, area1, bands1, list2, bands2, mslot, marea, mkeep;
+    } sgs[2];
+    dev_buf sg_allsums;
     pin_buf sgh_allsums;
+    hipStream_t seg_stream = nullptr;             // the P4Pf side of the rounds
+    hipEvent_t seg_ev[2] = {nullptr, nullptr};
     // hypotheses
     uint32_t hyp_count = 0;
     int solver = POSE_AMD_SOLVER_P4PF;
@@ -284,10 +289,15 @@ void pose_amd_destroy(pose_amd_ctx *c)
                        &c->maskw, &c->arows, &c->pstatus, &c->projf, &c->feat, &c->vlist, &c->vcount, &c->arows2, &c->pstatus2, &c->vlist2, &c->vcount2, &c->in0, &c->in1, &c->in2, &c->out0, &c->out1, &c->out2, &c->out3,
                        &c->cov_state, &c->cov_n, &c->cov_list1, &c->cov_bands1, &c->cov_area1, &c->cov_list2, &c->cov_bands2, &c->cov_mslot, &c->cov_marea,
                        &c->cov_mkeep, &c->knn_feat, &c->knn_image, &c->knn_fmax, &c->knn_q, &c->knn_part_s, &c->knn_part_i, &c->knn_idx, &c->knn_dist, &c->knn_good,
-                       &c->knn_flag, &c->knn_in0, &c->knn_in1, &c->sg_vlist, &c->sg_vcount, &c->sg_samples, &c->sg_sstatus, &c->sg_arows, &c->sg_pstatus, &c->sg_proj,
-                       &c->sg_pose, &c->sg_projf, &c->sg_nsol, &c->sg_counts, &c->sg_n, &c->sg_list1, &c->sg_area1, &c->sg_bands1, &c->sg_list2,
-                       &c->sg_bands2, &c->sg_mslot, &c->sg_marea, &c->sg_mkeep, &c->sg_allsums};
+                       &c->knn_flag, &c->knn_in0, &c->knn_in1, &c->sg_allsums};
     for (dev_buf *b : bufs) if (b->p) (void)hipFree(b->p);
+    for (pose_amd_ctx::seg_scratch &g : c->sgs) {
+        dev_buf *sb[] = {&g.vlist, &g.vcount, &g.samples, &g.sstatus, &g.arows, &g.pstatus, &g.proj, &g.pose, &g.projf, &g.nsol, &g.counts, &g.n, &g.list1, &g.area1,
+                         &g.bands1, &g.list2, &g.bands2, &g.mslot, &g.marea, &g.mkeep};
+        for (dev_buf *b : sb) if (b->p) (void)hipFree(b->p);
+    }
+    if (c->seg_stream) { (void)hipStreamSynchronize(c->seg_stream); (void)hipStreamDestroy(c->seg_stream); }
+    for (hipEvent_t e : c->seg_ev) if (e) (void)hipEventDestroy(e);
     if (c->qstage) (void)hipHostFree(c->qstage);
     pin_buf *pins[] = {&c->band_host, &c->h_words, &c->sgh_allsums};
     for (pin_buf *b : pins) if (b->p) (void)hipHostFree(b->p);
@@ -1188,7 +1198,7 @@ static int batch_fill(pose_amd_ctx *ctx, pose_amd_batch *b, int nq, const pose_a
     b->ctx = ctx;
     b->nq = 0;                                 // until everything below has succeeded
     const std::string pre = std::string(who) + ": query ";
-    struct place { size_t off, stride, cam_off_at, cam_ids_at; };
+    struct place { size_t off, stride, cam_off_at, cam_ids_at, sorted_at; };
     std::vector<place> at((size_t)nq);
     size_t total = 0;
     const bool all_cams = with_cams;
@@ -1215,6 +1225,8 @@ static int batch_fill(pose_amd_ctx *ctx, pose_amd_batch *b, int nq, const pose_a
         e.stride = (((size_t)q.n * 4) + 255) / 256 * 256;
         e.off = total;
         total += e.stride * (q.lindex ? 6 : 5);
+        e.sorted_at = total;                                       // copies in keypoint-row order for the coverage kernel
+        total += e.stride * 5;
         e.cam_off_at = e.cam_ids_at = 0;
         if (all_cams) {
             if (!q.cam_off || !q.cam_ids || q.cam_off[0] != 0) return fail(ctx, POSE_AMD_EINVAL, (pre + std::to_string(i) + ": set_camsets: no query or bad argument").c_str());
@@ -1300,7 +1312,30 @@ static int batch_fill(pose_amd_ctx *ctx, pose_amd_batch *b, int nq, const pose_a
                     int rb = (nhp - 8 - (h2 - 1)) & ~7;
                     rb = std::min(rb, (q.height + 7) & ~7);
                     static const bool off = getenv("POSE_AMD_SEG_COVER") && strcmp(getenv("POSE_AMD_SEG_COVER"), "bands") == 0;
-                    sq.cv_rows = (!off && q.n <= CVP_THREADS * CVP_KM && h2 >= 8 && rb >= 8 && q.width <= 16384 && q.height <= 16384) ? rb : 0;
+                    sq.cv_rows = (!off && q.n <= CVP_THREADS * CVP_KM && h2 >= 8 && rb >= 8 && q.width <= 16384 && q.height <= 16384 &&
+                                  cdiv(q.height, std::max(rb, 1)) <= CVP_PASSES) ? rb : 0;
+                    if (sq.cv_rows) {
+                        // correspondences in the order of their keypoint rows, and per pass the range of positions whose boxes can reach it
+                        std::vector<int> order((size_t)q.n), yr((size_t)q.n);
+                        for (int k = 0; k < q.n; ++k) { order[(size_t)k] = k; yr[(size_t)k] = (int)std::rint(std::max(-1.0e6f, std::min(1.0e6f, q.ky[k]))); }
+                        std::stable_sort(order.begin(), order.end(), [&](int a, int c) { return yr[(size_t)a] < yr[(size_t)c]; });
+                        float *dst = (float *)(hp + e.sorted_at);
+                        const size_t st = e.stride / 4;
+                        std::vector<int> ys((size_t)q.n);
+                        for (int k = 0; k < q.n; ++k) {
+                            const int o = order[(size_t)k];
+                            dst[k] = q.kx[o]; dst[st + k] = q.ky[o]; dst[2 * st + k] = q.X[o]; dst[3 * st + k] = q.Y[o]; dst[4 * st + k] = q.Z[o];
+                            ys[(size_t)k] = yr[(size_t)o];
+                        }
+                        const float *sd = (const float *)(dp + e.sorted_at);
+                        sq.skx = sd; sq.sky = sd + st; sq.sX = sd + 2 * st; sq.sY = sd + 3 * st; sq.sZ = sd + 4 * st;
+                        const int half = h2 / 2;
+                        for (int pass = 0, row0 = 0; row0 < q.height; ++pass, row0 += rb) {
+                            const int row1 = std::min(q.height, row0 + rb), y_base = row0 - half + 1, nh = (row1 - row0) + h2 - 1;
+                            sq.cv_lo[pass] = (unsigned short)(std::lower_bound(ys.begin(), ys.end(), y_base) - ys.begin());
+                            sq.cv_hi[pass] = (unsigned short)(std::lower_bound(ys.begin(), ys.end(), y_base + nh) - ys.begin());
+                        }
+                    }
                 }
                 if (all_cams) {
                     memcpy(hp + e.cam_off_at, q.cam_off, ((size_t)q.n + 1) * 4);
@@ -1492,6 +1527,20 @@ static int batch_run_segmented(pose_amd_batch *b, int sample_mode, uint64_t seed
         if (sscanf(e, "%d,%d", &a1, &a2) == 2 && a1 > 0 && a2 > 0) { cov_blocks[0] = std::min(a1, 64); cov_blocks[1] = std::min(a2, 64); }
     }
 
+    // The two solvers' halves of a round are independent chains of launches: the P3P queries run on the
+    // context's stream, the P4Pf queries on a second one (measurement runs keep one stream, whose
+    // events then bracket every kernel).
+    const bool two_streams = !b->timing && !stats && nsolver[0] > 0 && nsolver[1] > 0 && !(getenv("POSE_AMD_SEG_STREAMS") && atoi(getenv("POSE_AMD_SEG_STREAMS")) == 1);
+    hipStream_t streams[2] = {ctx->stream, ctx->stream};
+    if (two_streams) {
+        if (!ctx->seg_stream) {
+            HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->seg_stream, hipStreamNonBlocking));
+            for (hipEvent_t &e : ctx->seg_ev) HIPCHK(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        }
+        streams[1] = ctx->seg_stream;
+        HIPCHK(ctx, hipEventRecord(ctx->seg_ev[0], ctx->stream));                  // tables, lists, zeroed state
+        HIPCHK(ctx, hipStreamWaitEvent(ctx->seg_stream, ctx->seg_ev[0], 0));
+    }
     uint32_t step0 = 0, next_len = early ? first_len : 16384u;
     while (step0 < budget) {
         const uint32_t valid = std::min(next_len, budget - step0);
@@ -1499,7 +1548,9 @@ static int batch_run_segmented(pose_amd_batch *b, int sample_mode, uint64_t seed
         for (int solver = 0; solver < 2; ++solver) {
             if (nsolver[solver] == 0) continue;
             const int maxsol = solver ? P4PF_MAXSOL : P3P_MAXSOL;
-            hipLaunchKernelGGL(k_seg_compact, dim3(1), dim3(COVSEL_THREADS), 0, ctx->stream, (const seg_query *)b->qtab.p, (const int *)cand_dev[solver],
+            pose_amd_ctx::seg_scratch &G = ctx->sgs[solver];
+            hipStream_t stream = streams[solver];
+            hipLaunchKernelGGL(k_seg_compact, dim3(1), dim3(COVSEL_THREADS), 0, stream, (const seg_query *)b->qtab.p, (const int *)cand_dev[solver],
                                nsolver[solver], (const unsigned long long *)b->state.p, early ? 1 : 0, active_dev[solver], nact_dev[solver], (int)valid, issued_dev + solver);
             if ((rc = mark(6))) return rc;
             const size_t per_hyp = (size_t)maxsol * (96 + 104 + 128 + 4) + 16 + 4 + 4 + (solver ? P4PF_TAIL * 8 + 4 : 0);
@@ -1507,87 +1558,87 @@ static int batch_run_segmented(pose_amd_batch *b, int sample_mode, uint64_t seed
             const int per_pass = (int)std::max<size_t>(1, std::min<size_t>((size_t)nsolver[solver], std::min<size_t>(32768, pass_bytes / ((size_t)S * per_hyp))));
             for (int a0 = 0; a0 < nsolver[solver]; a0 += per_pass) {
                 const size_t na = (size_t)std::min(per_pass, nsolver[solver] - a0), nh = na * S, ns = nh * maxsol;
-                if ((rc = ensure(ctx, ctx->sg_samples, nh * 16)) || (rc = ensure(ctx, ctx->sg_sstatus, nh * 4)) || (rc = ensure(ctx, ctx->sg_proj, ns * 96)) ||
-                    (rc = ensure(ctx, ctx->sg_pose, ns * 104)) || (rc = ensure(ctx, ctx->sg_projf, ns * 128)) || (rc = ensure(ctx, ctx->sg_nsol, nh * 4)) ||
-                    (rc = ensure(ctx, ctx->sg_counts, ns * 4)) || (rc = ensure(ctx, ctx->sg_n, na * 16)) || (rc = ensure(ctx, ctx->sg_list1, na * cap1 * 4)) ||
-                    (rc = ensure(ctx, ctx->sg_area1, na * cap1 * 16)) || (rc = ensure(ctx, ctx->sg_bands1, na * cap1 * bands_max * 8)) ||
-                    (rc = ensure(ctx, ctx->sg_list2, na * cap2 * 4)) || (rc = ensure(ctx, ctx->sg_bands2, na * cap2 * bands_max * 8)) ||
-                    (rc = ensure(ctx, ctx->sg_mslot, na * (cap1 + cap2) * 4)) || (rc = ensure(ctx, ctx->sg_marea, na * (cap1 + cap2) * 8)) ||
-                    (rc = ensure(ctx, ctx->sg_mkeep, na * (cap1 + cap2))))
+                if ((rc = ensure(ctx, G.samples, nh * 16)) || (rc = ensure(ctx, G.sstatus, nh * 4)) || (rc = ensure(ctx, G.proj, ns * 96)) ||
+                    (rc = ensure(ctx, G.pose, ns * 104)) || (rc = ensure(ctx, G.projf, ns * 128)) || (rc = ensure(ctx, G.nsol, nh * 4)) ||
+                    (rc = ensure(ctx, G.counts, ns * 4)) || (rc = ensure(ctx, G.n, na * 16)) || (rc = ensure(ctx, G.list1, na * cap1 * 4)) ||
+                    (rc = ensure(ctx, G.area1, na * cap1 * 16)) || (rc = ensure(ctx, G.bands1, na * cap1 * bands_max * 8)) ||
+                    (rc = ensure(ctx, G.list2, na * cap2 * 4)) || (rc = ensure(ctx, G.bands2, na * cap2 * bands_max * 8)) ||
+                    (rc = ensure(ctx, G.mslot, na * (cap1 + cap2) * 4)) || (rc = ensure(ctx, G.marea, na * (cap1 + cap2) * 8)) ||
+                    (rc = ensure(ctx, G.mkeep, na * (cap1 + cap2))))
                     return rc;
-                if (solver && ((rc = ensure(ctx, ctx->sg_arows, nh * P4PF_TAIL * 8)) || (rc = ensure(ctx, ctx->sg_pstatus, nh * 4)))) return rc;
+                if (solver && ((rc = ensure(ctx, G.arows, nh * P4PF_TAIL * 8)) || (rc = ensure(ctx, G.pstatus, nh * 4)))) return rc;
                 seg_launch L{(const seg_query *)b->qtab.p, (const int *)active_dev[solver], (const int *)nact_dev[solver], a0, S, (int)valid, step0};
-                uint32_t *samples = (uint32_t *)ctx->sg_samples.p;
-                double *proj = (double *)ctx->sg_proj.p, *pose = (double *)ctx->sg_pose.p;
-                float *projf = use_mfma ? nullptr : (float *)ctx->sg_projf.p;      // the float32 pose copies serve the packed screen only
-                int *nsol = (int *)ctx->sg_nsol.p, *counts = (int *)ctx->sg_counts.p;
+                uint32_t *samples = (uint32_t *)G.samples.p;
+                double *proj = (double *)G.proj.p, *pose = (double *)G.pose.p;
+                float *projf = use_mfma ? nullptr : (float *)G.projf.p;      // the float32 pose copies serve the packed screen only
+                int *nsol = (int *)G.nsol.p, *counts = (int *)G.counts.p;
                 if (advanced)
                     hipLaunchKernelGGL(k_seg_sample_advanced, dim3(cdiv(valid, SAMPLE_ADV_WAVES), (unsigned)na), dim3(64 * SAMPLE_ADV_WAVES),
-                                       (size_t)SAMPLE_ADV_WAVES * std::max(b->bm_max, 1) * 4, ctx->stream, L, seed, (const double *)ctx->gain.p, samples,
-                                       (int *)ctx->sg_sstatus.p, std::max(b->bm_max, 1));
+                                       (size_t)SAMPLE_ADV_WAVES * std::max(b->bm_max, 1) * 4, stream, L, seed, (const double *)ctx->gain.p, samples,
+                                       (int *)G.sstatus.p, std::max(b->bm_max, 1));
                 else
-                    hipLaunchKernelGGL(k_seg_sample_basic, dim3(cdiv(valid, 256), (unsigned)na), dim3(256), 0, ctx->stream, L, seed, samples);
+                    hipLaunchKernelGGL(k_seg_sample_basic, dim3(cdiv(valid, 256), (unsigned)na), dim3(256), 0, stream, L, seed, samples);
                 if ((rc = mark(0))) return rc;
                 if (solver) {
                     // batch size as in launch_p4pf: 32 systems per block unless that leaves wave slots of the chip empty
                     const int wslots = (ctx->cus ? ctx->cus : 256) * 8;
                     const int batch = std::max(4, std::min(4 * cdiv(cdiv((long long)na * valid, wslots), 4), ELIM_BATCH));
-                    hipLaunchKernelGGL(k_seg_p4pf_elim, dim3(cdiv(valid, batch), (unsigned)na), dim3(64), 0, ctx->stream, L, (const uint32_t *)samples,
-                                       (double *)ctx->sg_arows.p, (int *)ctx->sg_pstatus.p, batch);
+                    hipLaunchKernelGGL(k_seg_p4pf_elim, dim3(cdiv(valid, batch), (unsigned)na), dim3(64), 0, stream, L, (const uint32_t *)samples,
+                                       (double *)G.arows.p, (int *)G.pstatus.p, batch);
                     if ((rc = mark(2))) return rc;
-                    hipLaunchKernelGGL(k_seg_p4pf_finish, dim3(cdiv(valid, 64), (unsigned)na), dim3(64), 0, ctx->stream, L, (const uint32_t *)samples,
-                                       (const double *)ctx->sg_arows.p, (const int *)ctx->sg_pstatus.p, proj, pose, nsol, projf, prm->eps);
+                    hipLaunchKernelGGL(k_seg_p4pf_finish, dim3(cdiv(valid, 64), (unsigned)na), dim3(64), 0, stream, L, (const uint32_t *)samples,
+                                       (const double *)G.arows.p, (const int *)G.pstatus.p, proj, pose, nsol, projf, prm->eps);
                     if ((rc = mark(3))) return rc;
                 } else {
-                    hipLaunchKernelGGL(k_seg_solve_p3p, dim3(cdiv(valid, 64), (unsigned)na), dim3(64), 0, ctx->stream, L, (const uint32_t *)samples, proj, pose, nsol, projf,
+                    hipLaunchKernelGGL(k_seg_solve_p3p, dim3(cdiv(valid, 64), (unsigned)na), dim3(64), 0, stream, L, (const uint32_t *)samples, proj, pose, nsol, projf,
                                        prm->eps);
                     if ((rc = mark(1))) return rc;
                 }
                 if (use_mfma) {
                     // the matrix-core screen: list of the valid slots of every query, then blocks of two waves (128 poses)
-                    if ((rc = ensure(ctx, ctx->sg_vlist, ns * 4)) || (rc = ensure(ctx, ctx->sg_vcount, na * 4))) return rc;
-                    HIPCHK(ctx, hipMemsetAsync(ctx->sg_vcount.p, 0, na * 4, ctx->stream));
-                    hipLaunchKernelGGL(k_seg_compact_valid, dim3(cdiv((long long)valid * maxsol, MS_COMPACT_SLOTS), (unsigned)na), dim3(256), 0, ctx->stream, L, maxsol,
-                                       (const int *)nsol, (int *)ctx->sg_vlist.p, (unsigned int *)ctx->sg_vcount.p, counts);
+                    if ((rc = ensure(ctx, G.vlist, ns * 4)) || (rc = ensure(ctx, G.vcount, na * 4))) return rc;
+                    HIPCHK(ctx, hipMemsetAsync(G.vcount.p, 0, na * 4, stream));
+                    hipLaunchKernelGGL(k_seg_compact_valid, dim3(cdiv((long long)valid * maxsol, MS_COMPACT_SLOTS), (unsigned)na), dim3(256), 0, stream, L, maxsol,
+                                       (const int *)nsol, (int *)G.vlist.p, (unsigned int *)G.vcount.p, counts);
                     hipLaunchKernelGGL((k_seg_score_mfma<SEG_MFMA_WAVES, SEG_MFMA_CHUNK>), dim3(cdiv((long long)valid * maxsol, SEG_MFMA_WAVES * 64), (unsigned)na),
-                                       dim3(SEG_MFMA_WAVES * 64), 0, ctx->stream, L, maxsol, (const double *)proj, (const int *)ctx->sg_vlist.p,
-                                       (const unsigned int *)ctx->sg_vcount.p, prm->eps, counts);
+                                       dim3(SEG_MFMA_WAVES * 64), 0, stream, L, maxsol, (const double *)proj, (const int *)G.vlist.p,
+                                       (const unsigned int *)G.vcount.p, prm->eps, counts);
                 } else {
                     // slots per block as in launch_score: as many as possible while the launch keeps about four blocks per compute unit
                     int spb = SCORE_SPB;
                     while (spb > 8 && (long long)na * cdiv((long long)valid * maxsol, spb) < (ctx->cus ? ctx->cus : 256) * 4) spb >>= 1;
-                    hipLaunchKernelGGL(k_seg_score_screen, dim3(cdiv((long long)valid * maxsol, spb), (unsigned)na), dim3(SCORE_THREADS), 0, ctx->stream, L, maxsol,
+                    hipLaunchKernelGGL(k_seg_score_screen, dim3(cdiv((long long)valid * maxsol, spb), (unsigned)na), dim3(SCORE_THREADS), 0, stream, L, maxsol,
                                        (const double *)proj, (const float *)projf, (const int *)nsol, prm->eps, counts, spb);
                 }
                 if ((rc = mark(4))) return rc;
-                seg_cov C{(unsigned long long *)b->state.p, (int *)ctx->sg_n.p, (int *)ctx->sg_list1.p, (long long *)ctx->sg_area1.p,
-                          (unsigned long long *)ctx->sg_bands1.p, cap1, (int *)ctx->sg_list2.p, (unsigned long long *)ctx->sg_bands2.p, cap2,
-                          (int *)ctx->sg_mslot.p, (long long *)ctx->sg_marea.p, (unsigned char *)ctx->sg_mkeep.p, bands_max};
-                hipLaunchKernelGGL(k_seg_cov_records, dim3((unsigned)na), dim3(COVSEL_THREADS), 0, ctx->stream, L, C, (const int *)counts, (const int *)nsol);
+                seg_cov C{(unsigned long long *)b->state.p, (int *)G.n.p, (int *)G.list1.p, (long long *)G.area1.p,
+                          (unsigned long long *)G.bands1.p, cap1, (int *)G.list2.p, (unsigned long long *)G.bands2.p, cap2,
+                          (int *)G.mslot.p, (long long *)G.marea.p, (unsigned char *)G.mkeep.p, bands_max};
+                hipLaunchKernelGGL(k_seg_cov_records, dim3((unsigned)na), dim3(COVSEL_THREADS), 0, stream, L, C, (const int *)counts, (const int *)nsol);
                 if ((rc = mark(6))) return rc;
                 if (b->any_band_cover)
-                    hipLaunchKernelGGL(k_seg_coverage, dim3(cov_blocks[0], bands_max, (unsigned)na), dim3(256), b->lds_cov, ctx->stream, L, C, 0, (const double *)proj, prm->eps);
+                    hipLaunchKernelGGL(k_seg_coverage, dim3(cov_blocks[0], bands_max, (unsigned)na), dim3(256), b->lds_cov, stream, L, C, 0, (const double *)proj, prm->eps);
                 if (b->lds_pose)
-                    hipLaunchKernelGGL(k_seg_cover_pose, dim3(pose_blocks[0], pose_blocks[2], (unsigned)na), dim3(CVP_THREADS), b->lds_pose, ctx->stream, L, C, 0, (const double *)proj, prm->eps);
+                    hipLaunchKernelGGL(k_seg_cover_pose, dim3(pose_blocks[0], pose_blocks[2], (unsigned)na), dim3(CVP_THREADS), b->lds_pose, stream, L, C, 0, (const double *)proj, prm->eps);
                 if ((rc = mark(5))) return rc;
-                hipLaunchKernelGGL(k_seg_cov_candidates, dim3((unsigned)na), dim3(COVSEL_THREADS), 0, ctx->stream, L, C, early ? 1 : 0, (const int *)counts,
+                hipLaunchKernelGGL(k_seg_cov_candidates, dim3((unsigned)na), dim3(COVSEL_THREADS), 0, stream, L, C, early ? 1 : 0, (const int *)counts,
                                    (const int *)nsol);
                 if ((rc = mark(6))) return rc;
                 if (b->any_band_cover)
-                    hipLaunchKernelGGL(k_seg_coverage, dim3(cov_blocks[1], bands_max, (unsigned)na), dim3(256), b->lds_cov, ctx->stream, L, C, 1, (const double *)proj, prm->eps);
+                    hipLaunchKernelGGL(k_seg_coverage, dim3(cov_blocks[1], bands_max, (unsigned)na), dim3(256), b->lds_cov, stream, L, C, 1, (const double *)proj, prm->eps);
                 if (b->lds_pose)
-                    hipLaunchKernelGGL(k_seg_cover_pose, dim3(pose_blocks[1], pose_blocks[3], (unsigned)na), dim3(CVP_THREADS), b->lds_pose, ctx->stream, L, C, 1, (const double *)proj, prm->eps);
+                    hipLaunchKernelGGL(k_seg_cover_pose, dim3(pose_blocks[1], pose_blocks[3], (unsigned)na), dim3(CVP_THREADS), b->lds_pose, stream, L, C, 1, (const double *)proj, prm->eps);
                 if ((rc = mark(5))) return rc;
-                hipLaunchKernelGGL(k_seg_cov_final, dim3((unsigned)na), dim3(COVSEL_THREADS), 0, ctx->stream, L, C, early ? 1 : 0, (const int *)counts,
+                hipLaunchKernelGGL(k_seg_cov_final, dim3((unsigned)na), dim3(COVSEL_THREADS), 0, stream, L, C, early ? 1 : 0, (const int *)counts,
                                    (const int *)nsol, (const double *)pose, (const double *)proj, (unsigned long long *)b->totals.p, issued_dev + 2);
                 HIPCHK(ctx, hipGetLastError());
                 if ((rc = mark(6))) return rc;
                 if (stats) {                                   // list lengths of the pass (this waits for the device)
                     std::vector<int> nn(na * 4, 0);
                     int nact = 0;
-                    HIPCHK(ctx, hipMemcpyAsync(nn.data(), ctx->sg_n.p, na * 16, hipMemcpyDeviceToHost, ctx->stream));
-                    HIPCHK(ctx, hipMemcpyAsync(&nact, nact_dev[solver], 4, hipMemcpyDeviceToHost, ctx->stream));
-                    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+                    HIPCHK(ctx, hipMemcpyAsync(nn.data(), G.n.p, na * 16, hipMemcpyDeviceToHost, stream));
+                    HIPCHK(ctx, hipMemcpyAsync(&nact, nact_dev[solver], 4, hipMemcpyDeviceToHost, stream));
+                    HIPCHK(ctx, hipStreamSynchronize(stream));
                     long long s1 = 0, s2 = 0;
                     int m1 = 0, m2 = 0;
                     const int lim = std::max(0, std::min((int)na, nact - a0));
@@ -1599,6 +1650,10 @@ static int batch_run_segmented(pose_amd_batch *b, int sample_mode, uint64_t seed
         }
         step0 += valid;
         next_len = std::min<uint32_t>(16384u, next_len * growth);
+    }
+    if (two_streams) {
+        HIPCHK(ctx, hipEventRecord(ctx->seg_ev[1], ctx->seg_stream));
+        HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->seg_ev[1], 0));
     }
     lap("issued");
     // ---- outcome -------------------------------------------------------------------------------------
