@@ -253,12 +253,14 @@ def per_query_sequence(ctx, q, sample_mode, seed, budget, early):
 
 
 def mixed_queries():
-    """Known and unknown focal lengths, image shapes whose coverage map does and does not fit the
-    row-union kernel, one query of nine matches, one whose inliers are too few to end the loop in
-    the first round of 1 024 steps, and one with a shared-keypoint index."""
+    """Known and unknown focal lengths, several image shapes, one query of nine matches, queries whose
+    inliers are too few to end the loop in the first round, one with a shared-keypoint index, and two
+    whose coverage areas come from the band kernel instead of the one-block-per-pose kernel."""
     spec = [(900, 0.3, False, 1600, 1200), (700, 0.5, True, 1200, 800), (1500, 0.05, False, 1600, 1066), (64, 0.9, True, 640, 480),
             (9, 1.0, False, 1600, 1200), (1200, 0.2, True, 486, 648), (2500, 0.04, False, 1024, 768), (500, 0.4, True, 1600, 1064),
-            (1100, 0.15, False, 1066, 1600), (3000, 0.03, True, 1600, 1200)]
+            (1100, 0.15, False, 1066, 1600), (3000, 0.03, True, 1600, 1200),
+            # more correspondences than the one-block-per-pose coverage kernel holds, and boxes too small for it: the band kernel
+            (6500, 0.05, True, 1600, 1200), (400, 0.3, False, 120, 90)]
     out = []
     for i, (n, frac, known, w, h) in enumerate(spec):
         q = synth.make_query(n, frac, 900 + i, width=w, height=h, known_focal=known)
