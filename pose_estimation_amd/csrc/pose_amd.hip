@@ -1197,6 +1197,11 @@ static int batch_fill(pose_amd_ctx *ctx, pose_amd_batch *b, int nq, const pose_a
 {
     b->ctx = ctx;
     b->nq = 0;                                 // until everything below has succeeded
+    const bool stats = getenv("POSE_AMD_SEG_STATS") != nullptr;          // development aid: phase times on stderr
+    const auto t_begin = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (stats) fprintf(stderr, "fill: %-10s at %.3f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count());
+    };
     const std::string pre = std::string(who) + ": query ";
     struct place { size_t off, stride, cam_off_at, cam_ids_at, sorted_at; };
     std::vector<place> at((size_t)nq);
@@ -1248,6 +1253,7 @@ static int batch_fill(pose_amd_ctx *ctx, pose_amd_batch *b, int nq, const pose_a
         }
     }
     int rc;
+    lap("validated");
     if ((rc = ensure(ctx, b->qpack, total)) || (rc = ensure_pinned(ctx, b->hpack, total)) || (rc = ensure(ctx, b->qtab, (size_t)nq * sizeof(seg_query))) ||
         (rc = ensure_pinned(ctx, b->h_qtab, (size_t)nq * sizeof(seg_query))) || (rc = ensure(ctx, b->lists, (size_t)nq * 16 + 64)) ||
         (rc = ensure_pinned(ctx, b->h_lists, (size_t)nq * 8)) || (rc = ensure(ctx, b->state, (size_t)nq * 33 * 8)) ||
@@ -1262,6 +1268,7 @@ static int batch_fill(pose_amd_ctx *ctx, pose_amd_batch *b, int nq, const pose_a
     {
         std::atomic<int> next(0);
         auto pack = [&]() {
+            std::vector<int> scratch_y, scratch_start, scratch_ys;
             for (;;) {
                 const int i = next.fetch_add(1);
                 if (i >= nq) return;
@@ -1316,14 +1323,21 @@ static int batch_fill(pose_amd_ctx *ctx, pose_amd_batch *b, int nq, const pose_a
                                   cdiv(q.height, std::max(rb, 1)) <= CVP_PASSES) ? rb : 0;
                     if (sq.cv_rows) {
                         // correspondences in the order of their keypoint rows, and per pass the range of positions whose boxes can reach it
-                        std::vector<int> order((size_t)q.n), yr((size_t)q.n);
-                        for (int k = 0; k < q.n; ++k) { order[(size_t)k] = k; yr[(size_t)k] = (int)std::rint(std::max(-1.0e6f, std::min(1.0e6f, q.ky[k]))); }
-                        std::stable_sort(order.begin(), order.end(), [&](int a, int c) { return yr[(size_t)a] < yr[(size_t)c]; });
+                        // (a counting sort over the image rows; keypoints far outside the image, whose boxes are
+                        // empty anyway, go to the first or the last bucket)
+                        const int half_box = h2 / 2, key_lo = -half_box - 1, nkeys = q.height + 2 * half_box + 3;
+                        std::vector<int> &yr = scratch_y, &start = scratch_start, &ys = scratch_ys;
+                        yr.resize((size_t)q.n); ys.resize((size_t)q.n); start.assign((size_t)nkeys + 1, 0);
+                        for (int k = 0; k < q.n; ++k) {
+                            const float yc = q.ky[k] == q.ky[k] ? std::max(-1.0e6f, std::min(1.0e6f, q.ky[k])) : -1.0e6f;
+                            yr[(size_t)k] = std::max(key_lo, std::min(key_lo + nkeys - 1, (int)std::rint(yc)));
+                            ++start[(size_t)(yr[(size_t)k] - key_lo) + 1];
+                        }
+                        for (int k = 0; k < nkeys; ++k) start[(size_t)k + 1] += start[(size_t)k];
                         float *dst = (float *)(hp + e.sorted_at);
                         const size_t st = e.stride / 4;
-                        std::vector<int> ys((size_t)q.n);
-                        for (int k = 0; k < q.n; ++k) {
-                            const int o = order[(size_t)k];
+                        for (int o = 0; o < q.n; ++o) {
+                            const int k = start[(size_t)(yr[(size_t)o] - key_lo)]++;
                             dst[k] = q.kx[o]; dst[st + k] = q.ky[o]; dst[2 * st + k] = q.X[o]; dst[3 * st + k] = q.Y[o]; dst[4 * st + k] = q.Z[o];
                             ys[(size_t)k] = yr[(size_t)o];
                         }
@@ -1348,12 +1362,13 @@ static int batch_fill(pose_amd_ctx *ctx, pose_amd_batch *b, int nq, const pose_a
                 }
             }
         };
-        const int nt = std::max(1, std::min(8, nq / 8));
+        const int nt = std::max(1, std::min(std::min(16, (int)std::thread::hardware_concurrency()), nq / 8));
         std::vector<std::thread> pool;
         for (int t = 1; t < nt; ++t) pool.emplace_back(pack);
         pack();
         for (std::thread &t : pool) t.join();
     }
+    lap("packed");
     if (bad_geometry.load()) return fail(ctx, POSE_AMD_EINVAL, "coverage: image wider than 393216 px");
     b->lds_cov = 0; b->bands_max = 1; b->bm_max = 0; b->lds_pose = 0; b->any_band_cover = false;
     for (int i = 0; i < nq; ++i) {
@@ -1418,6 +1433,7 @@ static int batch_fill(pose_amd_ctx *ctx, pose_amd_batch *b, int nq, const pose_a
     const unsigned long long *sums = (const unsigned long long *)ctx->sgh_allsums.p;
     for (int i = 0; i < nq; ++i)
         for (int k = 0; k < b->qt[(size_t)i].bands; ++k) b->area_all[(size_t)i] += (int64_t)sums[(size_t)i * b->bands_max + k];
+    lap("uploaded");
     b->nq = nq;
     return POSE_AMD_OK;
 }
