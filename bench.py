@@ -450,14 +450,13 @@ def bench_dubrovnik(args):
                                          sum(1 for i in range(nq) if shapes[i % len(shapes)][2] == 0), mode),
                           "parallelism": "queries partitioned over %d GPU(s), %s" % (
                               world, "%d host threads (contexts) per GPU" % T if not batched
-                              else "%d worker threads / streams per GPU inside the library (one launch sequence per query)" % T if select == SELECT_INLIERS
                               else "all queries of a GPU share their launches (rounds of 128, 640, 3200, ... steps, list of running queries kept on the device)"),
                           "queries": "resident in HBM (pose_amd_batch_create before the timed region, pose_amd_batch_run timed)" if resident is not None
                                      else "host arrays handed over in every pass (packing + PCIe copy inside the timed region)",
                           "hypotheses_per_s": round(steps_total * args.steps / dt, 1),
                           "mean_steps_per_query": round(steps_total / max(len(res), 1), 1),
                           "queries_within_2_units_of_true_position": located}}
-        if world == 1 and resident is not None and select == SELECT_COVERAGE:
+        if world == 1 and resident is not None:
             out["roofline"] = roofline_shared_launches(resident, queries, res, sample_mode, select, args)
             if not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline_batch(ctxs[0], queries, args, select, sample_mode)

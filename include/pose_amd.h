@@ -164,11 +164,11 @@ typedef struct {
  * queries -- the loop of benchmark.cpp:24-36 in one call: per query pose_amd_set_query
  * [+ set_camsets] + pose_amd_sample(sample_mode, seed, query_id, 0, budget) +
  * pose_amd_ransac_run(params), with bit-identical results.
- * With the reference's selection (POSE_AMD_SELECT_COVERAGE) all queries share their launches:
- * rounds of 128, 640, 3 200, ... RANSAC steps run for every query whose loop has not ended, the
- * device keeps that list itself and the host waits once, at the end.  With inlier-count selection
- * (or POSE_AMD_BATCH=threads in the environment) internal worker threads, each with its own
- * stream (count from POSE_AMD_BATCH_LANES, default 8), run one launch sequence per query.
+ * All queries share their launches: rounds of 128, 640, 3 200, ... RANSAC steps run for every query
+ * whose loop has not ended, the device keeps that list itself and the host waits once, at the end
+ * (the P3P and the P4Pf queries on two streams).  With POSE_AMD_BATCH=threads in the environment
+ * internal worker threads, each with its own stream (count from POSE_AMD_BATCH_LANES, default 8),
+ * run one launch sequence per query instead.
  * results[nq].  The context's own resident query is not touched. */
 int pose_amd_ransac_batch(pose_amd_ctx *ctx, int nq, const pose_amd_query *queries, int sample_mode, uint64_t seed,
                           uint32_t budget, const pose_amd_params *params, pose_amd_result *results);

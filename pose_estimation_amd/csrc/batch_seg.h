@@ -521,4 +521,75 @@ __global__ __launch_bounds__(COVSEL_THREADS) void k_seg_cov_final(seg_launch L, 
     }
 }
 
+// Selection by inlier count for the queries of a pass (query_processor_basic.cpp:132-133, 214-225 with
+// the inlier count as the quality): one block per query.  With early exit the loop ends with the
+// step of the first pose that has >= thresh inliers; among the poses of the steps that ran, the
+// one with the most inliers (the earliest of equals) is kept if it beats the count carried in.
+// State words as k_seg_cov_final leaves them (word 0, the area, stays 0).
+__global__ __launch_bounds__(COVSEL_THREADS) void k_seg_select_inliers(seg_launch L, int early_exit, const int *__restrict__ counts, const int *__restrict__ nsol,
+                                                                        const double *__restrict__ pose, const double *__restrict__ proj,
+                                                                        unsigned long long *__restrict__ state_all, unsigned long long *__restrict__ totals)
+{
+    __shared__ unsigned long long s_key[COVSEL_THREADS / 64], s_first[COVSEL_THREADS / 64], s_nv[COVSEL_THREADS / 64];
+    __shared__ unsigned long long s_limit;
+    const int a = blockIdx.x;
+    if (!seg_live(L, a)) return;
+    const seg_query &sq = seg_of(L, a);
+    const int maxsol = sq.maxsol, nslots = L.V * maxsol;
+    const size_t base = (size_t)a * L.S, sbase = base * maxsol;
+    const int *cnt = counts + sbase, *ns = nsol + base;
+    unsigned long long *state = state_all + (size_t)seg_index(L, a) * 33;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // first slot whose pose reaches the threshold
+    unsigned long long first = ~0ull;
+    if (early_exit)
+        for (int s = tid; s < nslots; s += COVSEL_THREADS)
+            if ((s % maxsol) < ns[s / maxsol] && (unsigned)cnt[s] >= sq.thresh) { first = (unsigned long long)s; break; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const unsigned long long v = __shfl_xor(first, o); first = v < first ? v : first; }
+    if (lane == 0) s_first[wave] = first;
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < COVSEL_THREADS / 64; ++w) first = s_first[w] < first ? s_first[w] : first;
+        s_limit = first == ~0ull ? (unsigned long long)nslots : (first / (unsigned)maxsol + 1ull) * (unsigned)maxsol;
+        s_first[0] = first;
+    }
+    __syncthreads();
+    const int limit = (int)s_limit;
+    const bool done = s_first[0] != ~0ull;
+    unsigned long long key = 0, nv = 0;
+    for (int s = tid; s < limit; s += COVSEL_THREADS) {
+        if ((s % maxsol) >= ns[s / maxsol]) continue;
+        const unsigned long long k = ((unsigned long long)(unsigned)cnt[s] << 32) | (0xFFFFFFFFu - (unsigned)s);
+        key = k > key ? k : key;
+        ++nv;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const unsigned long long v = __shfl_xor(key, o); key = v > key ? v : key; nv += __shfl_xor(nv, o); }
+    if (lane == 0) { s_key[wave] = key; s_nv[wave] = nv; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < COVSEL_THREADS / 64; ++w) { key = s_key[w] > key ? s_key[w] : key; nv += s_nv[w]; }
+        const unsigned c = (unsigned)(key >> 32);
+        const unsigned long long steps = (unsigned long long)(limit / maxsol);
+        long long kept = -1;
+        if ((unsigned long long)c > state[1]) {              // strictly more inliers than every pose before (counts start from 0)
+            kept = (long long)(0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFu));
+            state[1] = c; state[2] = 1ull;
+        }
+        state[3] = steps; state[4] = nv; state[5] = done ? 1ull : 0ull; state[6] = kept >= 0 ? (unsigned long long)kept : ~0ull; state[7] = 0ull;
+        unsigned long long *t = totals + (size_t)seg_index(L, a) * 4;
+        t[0] += steps; t[1] += nv;
+        if (kept >= 0) t[2] = (((unsigned long long)L.step0 + (unsigned long long)kept / (unsigned)maxsol + 1ull) << 8) | ((unsigned long long)kept % (unsigned)maxsol);
+        s_limit = kept >= 0 ? (unsigned long long)kept : ~0ull;
+    }
+    __syncthreads();
+    if (s_limit != ~0ull) {
+        const size_t bs = sbase + (size_t)s_limit;
+        double *out = reinterpret_cast<double *>(state);
+        if (tid < 13) out[8 + tid] = pose[bs * 13 + tid];
+        if (tid < 12) out[21 + tid] = proj[bs * 12 + tid];
+    }
+}
+
 } // namespace pose_amd

@@ -1451,6 +1451,7 @@ static int batch_run_segmented(pose_amd_batch *b, int sample_mode, uint64_t seed
     const int nq = b->nq;
     const bool advanced = sample_mode == POSE_AMD_SAMPLE_ADVANCED;
     const bool early = prm->early_exit != 0;
+    const bool coverage = prm->select_mode == POSE_AMD_SELECT_COVERAGE;   // otherwise: selection by inlier count
     const bool stats = getenv("POSE_AMD_SEG_STATS") != nullptr;          // development aid: phase times on stderr
     const auto t_begin = std::chrono::steady_clock::now();
     auto lap = [&](const char *what) {
@@ -1616,9 +1617,14 @@ static int batch_run_segmented(pose_amd_batch *b, int sample_mode, uint64_t seed
                     HIPCHK(ctx, hipMemsetAsync(G.vcount.p, 0, na * 4, stream));
                     hipLaunchKernelGGL(k_seg_compact_valid, dim3(cdiv((long long)valid * maxsol, MS_COMPACT_SLOTS), (unsigned)na), dim3(256), 0, stream, L, maxsol,
                                        (const int *)nsol, (int *)G.vlist.p, (unsigned int *)G.vcount.p, counts);
-                    hipLaunchKernelGGL((k_seg_score_mfma<SEG_MFMA_WAVES, SEG_MFMA_CHUNK>), dim3(cdiv((long long)valid * maxsol, SEG_MFMA_WAVES * 64), (unsigned)na),
-                                       dim3(SEG_MFMA_WAVES * 64), 0, stream, L, maxsol, (const double *)proj, (const int *)G.vlist.p,
-                                       (const unsigned int *)G.vcount.p, prm->eps, counts);
+                    // long rounds give a query thousands of valid poses: the block shape of the per-query kernel (8 waves, 512 poses)
+                    if (valid >= 2048)
+                        hipLaunchKernelGGL((k_seg_score_mfma<MS_WAVES, MS_CHUNK_TILES>), dim3(cdiv((long long)valid * maxsol, MS_POSES), (unsigned)na), dim3(MS_THREADS), 0,
+                                           stream, L, maxsol, (const double *)proj, (const int *)G.vlist.p, (const unsigned int *)G.vcount.p, prm->eps, counts);
+                    else
+                        hipLaunchKernelGGL((k_seg_score_mfma<SEG_MFMA_WAVES, SEG_MFMA_CHUNK>), dim3(cdiv((long long)valid * maxsol, SEG_MFMA_WAVES * 64), (unsigned)na),
+                                           dim3(SEG_MFMA_WAVES * 64), 0, stream, L, maxsol, (const double *)proj, (const int *)G.vlist.p,
+                                           (const unsigned int *)G.vcount.p, prm->eps, counts);
                 } else {
                     // slots per block as in launch_score: as many as possible while the launch keeps about four blocks per compute unit
                     int spb = SCORE_SPB;
@@ -1627,6 +1633,13 @@ static int batch_run_segmented(pose_amd_batch *b, int sample_mode, uint64_t seed
                                        (const double *)proj, (const float *)projf, (const int *)nsol, prm->eps, counts, spb);
                 }
                 if ((rc = mark(4))) return rc;
+                if (!coverage) {
+                    hipLaunchKernelGGL(k_seg_select_inliers, dim3((unsigned)na), dim3(COVSEL_THREADS), 0, stream, L, early ? 1 : 0, (const int *)counts, (const int *)nsol,
+                                       (const double *)pose, (const double *)proj, (unsigned long long *)b->state.p, (unsigned long long *)b->totals.p);
+                    HIPCHK(ctx, hipGetLastError());
+                    if ((rc = mark(6))) return rc;
+                    continue;
+                }
                 seg_cov C{(unsigned long long *)b->state.p, (int *)G.n.p, (int *)G.list1.p, (long long *)G.area1.p,
                           (unsigned long long *)G.bands1.p, cap1, (int *)G.list2.p, (unsigned long long *)G.bands2.p, cap2,
                           (int *)G.mslot.p, (long long *)G.marea.p, (unsigned char *)G.mkeep.p, bands_max};
@@ -1698,7 +1711,7 @@ static int batch_run_segmented(pose_amd_batch *b, int sample_mode, uint64_t seed
         pose_amd_result &r = results[i];
         r.steps = (uint32_t)t[0];
         r.poses_scored = t[1];
-        r.area_all = b->area_all[(size_t)i];
+        r.area_all = coverage ? b->area_all[(size_t)i] : 0;
         if (t[2] != 0ull) {
             const double *pz = (const double *)(w + 8);
             r.found = 1;
@@ -1706,7 +1719,7 @@ static int batch_run_segmented(pose_amd_batch *b, int sample_mode, uint64_t seed
             memcpy(r.C, pz + 1, 24);
             memcpy(r.Rc, pz + 4, 72);
             r.inliers = (uint32_t)w[1];
-            r.area_fit = (int64_t)w[0];
+            r.area_fit = coverage ? (int64_t)w[0] : 0;
             r.best_hyp = (uint32_t)((t[2] >> 8) - 1ull);
             r.best_sol = (uint32_t)(t[2] & 0xffull);
         }
@@ -1790,13 +1803,12 @@ static int ransac_batch_threads(pose_amd_ctx *ctx, int nq, const pose_amd_query 
     return status.load();
 }
 
-// The reference's selection (coverage quality) runs many queries per launch; inlier-count selection
-// and POSE_AMD_BATCH=threads take one launch sequence per query on worker threads.
+// Many queries per launch; POSE_AMD_BATCH=threads takes one launch sequence per query on worker threads.
 static bool batch_shares_launches(int sample_mode, const pose_amd_params *prm)
 {
     static const bool off = getenv("POSE_AMD_BATCH") && strcmp(getenv("POSE_AMD_BATCH"), "threads") == 0;
-    return !off && prm->select_mode == POSE_AMD_SELECT_COVERAGE && prm->eps > 0 && prm->inlier_divisor != 0 &&
-           (sample_mode == POSE_AMD_SAMPLE_BASIC || sample_mode == POSE_AMD_SAMPLE_ADVANCED);
+    return !off && (prm->select_mode == POSE_AMD_SELECT_COVERAGE || prm->select_mode == POSE_AMD_SELECT_INLIERS) && prm->eps > 0 &&
+           prm->inlier_divisor != 0 && (sample_mode == POSE_AMD_SAMPLE_BASIC || sample_mode == POSE_AMD_SAMPLE_ADVANCED);
 }
 
 static int batch_run(pose_amd_batch *b, int sample_mode, uint64_t seed, uint32_t budget, const pose_amd_params *prm, pose_amd_result *results, const char *who)

@@ -244,12 +244,12 @@ def test_eigen_step_root_sets_on_benchmark_stream(ctx, record_property):
 RESULT_KEYS = ("found", "inliers", "steps", "best_hyp", "best_sol", "poses_scored", "area_fit", "area_all")
 
 
-def per_query_sequence(ctx, q, sample_mode, seed, budget, early):
+def per_query_sequence(ctx, q, sample_mode, seed, budget, early, select=SELECT_COVERAGE):
     ctx.set_query(*oracle_args(q), lindex=q.get("lindex"))
     if sample_mode == SAMPLE_ADVANCED:
         ctx.set_camsets(q["cam_off"], q["cam_ids"])
     ctx.sample(sample_mode, seed, q["query_id"], 0, budget, export=False)
-    return ctx.ransac_run(select_mode=SELECT_COVERAGE, early_exit=early)
+    return ctx.ransac_run(select_mode=select, early_exit=early)
 
 
 def mixed_queries():
@@ -275,21 +275,24 @@ def mixed_queries():
     return out
 
 
-@pytest.mark.parametrize("sample_mode,budget,early", [(SAMPLE_BASIC, 2500, True), (SAMPLE_BASIC, 1500, False), (SAMPLE_ADVANCED, 100, False),
-                                                       (SAMPLE_ADVANCED, 1100, True)])
-def test_multi_query_launches_equal_the_per_query_sequence(ctx, sample_mode, budget, early):
-    """pose_amd_ransac_batch with the reference's selection runs all queries of a batch in shared
-    launches (rounds of 1 024, 4 096, ... steps).  Every field of every result, the pose included,
-    is bit-identical to set_query + (set_camsets) + sample + ransac_run on that query alone."""
+@pytest.mark.parametrize("sample_mode,budget,early,select", [(SAMPLE_BASIC, 2500, True, SELECT_COVERAGE), (SAMPLE_BASIC, 1500, False, SELECT_COVERAGE),
+                                                              (SAMPLE_ADVANCED, 100, False, SELECT_COVERAGE), (SAMPLE_ADVANCED, 1100, True, SELECT_COVERAGE),
+                                                              (SAMPLE_BASIC, 2500, True, SELECT_INLIERS), (SAMPLE_BASIC, 700, False, SELECT_INLIERS),
+                                                              (SAMPLE_ADVANCED, 100, False, SELECT_INLIERS)])
+def test_multi_query_launches_equal_the_per_query_sequence(ctx, sample_mode, budget, early, select):
+    """pose_amd_ransac_batch runs all queries of a batch in shared launches (rounds of 128, 640,
+    3 200, ... steps), with the reference's selection and with selection by inlier count.  Every
+    field of every result, the pose included, is bit-identical to set_query + (set_camsets) + sample
+    + ransac_run on that query alone."""
     queries = mixed_queries()
-    got = ctx.ransac_batch(queries, sample_mode, seed=5, budget=budget, select_mode=SELECT_COVERAGE, early_exit=early)
+    got = ctx.ransac_batch(queries, sample_mode, seed=5, budget=budget, select_mode=select, early_exit=early)
     rounds = set()
     for q, g in zip(queries, got):
-        o = per_query_sequence(ctx, q, sample_mode, 5, budget, early)
+        o = per_query_sequence(ctx, q, sample_mode, 5, budget, early, select)
         for k in RESULT_KEYS:
             assert g[k] == o[k], (k, len(q["kx"]), g[k], o[k])
         assert np.array_equal(g["C"], o["C"]) and np.array_equal(g["Rc"], o["Rc"]) and g["focal"] == o["focal"]
-        rounds.add(0 if g["steps"] <= 1024 else 1 if g["steps"] <= 5120 else 2)
+        rounds.add(0 if g["steps"] <= 128 else 1 if g["steps"] <= 768 else 2)
     if early and budget > 1024:
         assert len(rounds) >= 2, rounds              # some queries end in the first round, some need the second
 
