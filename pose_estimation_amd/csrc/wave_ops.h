@@ -53,4 +53,21 @@ __device__ __forceinline__ int row16_argmax_abs(double x0, bool c0, double x1, b
     return sh + (int)__builtin_ctz(g);
 }
 
+// The same search over one value per lane (the rows of one slot): absolute lane number of the
+// candidate with the largest |x| inside the caller's row of 16 lanes; the lowest lane wins a tie.
+__device__ __forceinline__ int row16_argmax_abs1(double x, bool c, bool &none)
+{
+    const unsigned key = c ? (unsigned)__double2hiint(x) & 0x7fffffffu : 0u;
+    unsigned m = key;
+    m = max(m, (unsigned)__builtin_amdgcn_update_dpp(0, (int)m, 0xB1, 0xf, 0xf, true));
+    m = max(m, (unsigned)__builtin_amdgcn_update_dpp(0, (int)m, 0x4E, 0xf, 0xf, true));
+    m = max(m, (unsigned)__builtin_amdgcn_update_dpp(0, (int)m, 0x141, 0xf, 0xf, true));
+    m = max(m, (unsigned)__builtin_amdgcn_update_dpp(0, (int)m, 0x140, 0xf, 0xf, true));
+    const unsigned long long w = __builtin_amdgcn_ballot_w64(key == m);
+    const int sh = (int)(threadIdx.x & 48);
+    const unsigned g = (unsigned)(w >> sh) & 0xffffu;      // never empty: the maximum is attained
+    none = m < 0x00100000u;
+    return sh + (int)__builtin_ctz(g);
+}
+
 } // namespace pose_amd

@@ -5,7 +5,8 @@ eigen-decomposition for P4Pf, a closed-form quartic with sqrt(1 - x^2) back-subs
 P3P) lose more than that on ill-conditioned samples all by themselves: the double-precision
 oracle then differs from the SAME oracle evaluated in long double by e_ref > 1e-8.  A device
 result is accepted within max(1e-8, 20 e_ref) of the long-double oracle; samples on which the
-two oracles do not even agree on the number of solutions are reported as ungated."""
+two oracles do not even agree on the number of solutions are reported as ungated.  For P4Pf
+e_ref is taken over the sample and a few copies perturbed in the last place (see p4pf_gate)."""
 import numpy as np
 
 import oracle_lib as O
@@ -18,15 +19,28 @@ def relerr(a, b, floor=1e-6):
     return np.max(np.abs(a - b) / np.maximum(np.abs(b), floor)) if a.size else 0.0
 
 
+PERTURBED = 3      # extra runs of the double oracle on inputs moved by less than one unit in the last place
+
+
 def p4pf_gate(m, M):
     """-> (n, f, R, t of the long-double oracle, e_ref), or None when the double and the
-    long-double oracle disagree on the solution count."""
-    n, f, R, t = O.p4pf(m, M)
+    long-double oracle disagree on the solution count.  e_ref is the largest discrepancy between
+    the long-double result and the double oracle run on the sample itself and on PERTURBED copies
+    whose inputs are moved by at most 2^-52 relative: one run alone is one draw of the rounding
+    noise and underestimates what the sample's conditioning does to a different but equally valid
+    order of operations."""
     n2, f2, R2, t2 = O.p4pf(m, M, long_double=True)
-    if n != n2:
-        return None
-    e_ref = max(relerr(f, f2), relerr(R, R2, 1e-3), relerr(t, t2, 1e-3)) if n > 0 else 0.0
-    return n, f2, R2, t2, e_ref
+    rng = np.random.default_rng(20240229)
+    e_ref = 0.0
+    for k in range(PERTURBED + 1):
+        mm, MM = (m, M) if k == 0 else (m * (1.0 + rng.uniform(-1, 1, np.shape(m)) * 2.0 ** -52),
+                                        M * (1.0 + rng.uniform(-1, 1, np.shape(M)) * 2.0 ** -52))
+        n, f, R, t = O.p4pf(mm, MM)
+        if n != n2:
+            return None
+        if n > 0:
+            e_ref = max(e_ref, relerr(f, f2), relerr(R, R2, 1e-3), relerr(t, t2, 1e-3))
+    return n2, f2, R2, t2, e_ref
 
 
 def p3p_gate(f, P):

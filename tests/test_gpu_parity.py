@@ -139,7 +139,7 @@ def test_p4pf_batch_random(ctx):
         agree += p4pf_agrees(nsol[i], f[i], R[i], t[i], g)
         tight += g[4] < 1e-9
     assert gated >= 585 and tight >= 300 and near_double <= 6
-    assert agree >= gated - 3, (agree, gated)
+    assert agree >= gated - 2, (agree, gated)
 
 
 @pytest.mark.gpu

@@ -22,28 +22,28 @@ def test_schedule_shape():
     assert done == list(range(78))                     # every left-hand column is eliminated once
 
 
-def test_stage1_order_is_valid_and_in_lane_steps_are_co_located():
+def test_stage1_order_is_valid_and_slots_hold_the_two_groups():
     """A stage-1 pivot row must never have been a target of an earlier step (its entries are read
-    as plain coefficients), whatever order the pivots are taken in; the stage-2 steps marked
-    in-lane have exactly two candidate rows, in the two slots of one lane, which no other in-lane
-    step shares; positions are a permutation of 0..28."""
+    as plain coefficients), whatever order the pivots are taken in; positions are a permutation
+    of 0..15 and 16..; the candidate rows of a split-phase step all sit in the slot that runs it,
+    and a slot skips a stage-1 step only when none of its rows is a target."""
     s = G.build_schedule()
     touched = set()
     for st in s["steps"]:
         assert st["row"] not in touched
         touched |= set(st["targets"])
+        for slot in (0, 1):
+            assert st["slots"][slot] == any(s["slot_of"][t] == slot for t in st["targets"])
     pos = s["lane_of"]
-    assert sorted(pos.values()) == list(range(29))
-    used = set()
-    in_lane = [st for st in s["stage2"] if st.get("in_lane")]
-    assert len(in_lane) >= 2
-    for st in in_lane:
-        a, b = (pos[r] for r in st["cand"])
-        assert len(st["cand"]) == 2 and abs(a - b) == 16 and not ({a, b} & used)
-        used |= {a, b}
-    # in-lane steps come first: later steps may involve the rows they retire
-    flags = [bool(st.get("in_lane")) for st in s["stage2"]]
-    assert flags == sorted(flags, reverse=True)
+    assert len(set(pos.values())) == 29 and all(pos[r] // 16 == s["slot_of"][r] for r in pos)
+    for slot in (0, 1):
+        n = sum(1 for r in pos if s["slot_of"][r] == slot)
+        assert sorted(pos[r] for r in pos if s["slot_of"][r] == slot) == list(range(16 * slot, 16 * slot + n))
+    assert len(s["split"][0]) + len(s["split"][1]) == 12 and len(s["joint"]) == 12
+    for slot in (0, 1):
+        for i in s["split"][slot]:
+            assert all(s["slot_of"][r] == slot for r in s["stage2"][i]["cand"])
+    assert sorted(s["split"][0] + s["split"][1] + s["joint"]) == list(range(24))
 
 
 def test_schedule_reproduces_action_matrix_rows():
@@ -64,18 +64,27 @@ def test_schedule_reproduces_action_matrix_rows():
     assert np.median(errs) < 1e-10 and np.quantile(errs, 0.9) < 1e-8 and np.max(errs) < 1e-4, (np.median(errs), np.max(errs))
 
 
-def test_blocked_stage2_equals_step_by_step_elimination():
-    """The kernel takes the stage-2 pivots four at a time: panel steps on the block's own columns,
-    raw trailing rows of the pivots, effective multipliers m' = m L^-1, one update per block.
-    Same pivots, same result as publishing every pivot row at once (up to rounding that scales
-    with the conditioning of the sample); blocks cover every non-leading step exactly once and
-    no published row exceeds its LDS slot."""
+def test_generated_updates_equal_step_by_step_elimination():
+    """The kernel skips the stage-1 steps of a slot none of whose rows takes part, eliminates the
+    two independent groups of the split phase side by side (per-slot pivots, columns and trailing
+    columns) and takes its pivots in blocks: panel steps on the block's own columns, raw trailing
+    rows of the pivots, effective multipliers m' = m L^-1, one update per block.  Same pivots,
+    same result as the plain row-by-row elimination (up to rounding that scales with the
+    conditioning of the sample); blocks cover every step exactly once, a split block publishes at
+    most BLOCK rows and no published row exceeds its LDS slot."""
     s = G.build_schedule()
-    lead, blocks = G.stage2_blocks(s, G.BLOCK)
-    assert sorted(lead + [i for b in blocks for i in b["steps"]]) == list(range(24))
-    for b in blocks:
+    sb, jb = G.split_blocks(s, G.BLOCK), G.joint_blocks(s, G.BLOCK)
+    steps = [i for parts in sb for p in parts for i in p["steps"]] + [i for b in jb for i in b["steps"]]
+    assert sorted(steps) == list(range(24))
+    for parts in sb:
+        assert len(parts[0]["steps"]) + len(parts[1]["steps"]) <= G.BLOCK and parts[1]["base"] == len(parts[0]["steps"])
+        for p in parts:
+            assert not (set(p["cols"]) & set(p["trail"]))
+            if p["cols"]:
+                G.row_items(len(p["cols"]), p["trail"])       # asserts the row fits
+    for b in jb:
         assert not (set(b["cols"]) & set(b["trail"])) and set(G.KEEP + G.RHS) <= set(b["trail"])
-        assert (len(b["trail"]) + len(b["cols"])) * 8 <= G.ROW_BYTES
+        G.row_items(len(b["cols"]), b["trail"])
     m, M = synth.random_p4pf_problems(120, seed=19, contaminate=(0, 1, 2), noise=0.3)
     errs = []
     for i in range(120):
@@ -83,7 +92,7 @@ def test_blocked_stage2_equals_step_by_step_elimination():
         if n < 0:
             continue
         st1, A1 = G.simulate(s, k)
-        st2, A2 = G.simulate_blocked(s, k, G.BLOCK)
+        st2, A2 = G.simulate_kernel(s, k, G.BLOCK)
         assert st1 == 0 and st2 == 0
         errs.append(np.max(np.abs(A1 - A2)) / np.max(np.abs(A1)))
     errs = np.array(errs)
