@@ -501,29 +501,12 @@ def emit(sched):
     m1 = sum(1 << (L - 16) for L in surv if L >= 16)
     w(f"    bool act0 = ((0x{m0:x}u >> rl) & 1u) != 0, act1 = ((0x{m1:x}u >> rl) & 1u) != 0;")
 
-    def masked_stores(tag, vals, pkvar):
-        """The lanes with pkvar >= 0 store their row (vals: one expression per double) into LDS row
-        pkvar of the block.  exec-masked ds_write_b128 in inline assembly: a divergent `if` would
-        split the kernel's single basic block and wreck register allocation."""
-        npairs = len(vals) // 2
-        for j in range(npairs):
-            w(f"        const v2f64 {tag}{j} = {{{vals[2 * j]}, {vals[2 * j + 1]}}};")
-        w(f"        const unsigned long long wm{tag} = __builtin_amdgcn_ballot_w64({pkvar} >= 0);")
-        w(f"        const unsigned addr{tag} = pbuf_addr + (unsigned)({pkvar} < 0 ? 0 : {pkvar}) * {ROW_BYTES}u;")
-        for g0 in range(0, npairs, 6):
-            grp = list(range(g0, min(g0 + 6, npairs)))
-            lines = ['"s_mov_b64 exec, %[mask]\\n\\t"']
-            for j in grp:
-                lines.append(f'"ds_write_b128 %[addr], %[a{j - g0}] offset:{16 * j}\\n\\t"')
-            lines.append('"s_mov_b64 exec, -1"')
-            w("        asm volatile(" + "\n                     ".join(lines))
-            ops = ", ".join(f'[a{j - g0}] "v"({tag}{j})' for j in grp)
-            w(f'                     :: [mask] "s"(wm{tag}), [addr] "v"(addr{tag}), {ops} : "memory");')
-
     def masked_stores_direct(tag, items, s, pkvar):
-        """The same for rows that come from one slot: the doubles go out as they sit in their
-        registers, two per ds_write2_b64 (two separate data operands, so nothing has to be packed
-        into consecutive registers first); padding entries are never read and are not written."""
+        """The lanes with pkvar >= 0 store their slot-s row into LDS row pkvar of the block.  The
+        doubles go out as they sit in their registers, two per ds_write2_b64 (two separate data
+        operands, so nothing has to be packed into consecutive registers first); padding entries are
+        never read and are not written.  exec-masked stores in inline assembly: a divergent `if`
+        would split the kernel's single basic block and wreck register allocation."""
         real = [(t, (f"m{x}_{s}" if kind == "m" else f"r{x}_{s}")) for t, (kind, x) in enumerate(items) if kind != "z"]
         w(f"        const unsigned long long wm{tag} = __builtin_amdgcn_ballot_w64({pkvar} >= 0);")
         w(f"        const unsigned addr{tag} = pbuf_addr + (unsigned)({pkvar} < 0 ? 0 : {pkvar}) * {ROW_BYTES}u;")
@@ -584,42 +567,45 @@ def emit(sched):
     def apply_block(tag, base, nb, trail, first, slots):
         """Effective multipliers m' = m L^-1 (back substitution, L from the heads of the published
         rows) and the update of the trailing columns of `slots` with the block's nb pivot rows,
-        which sit in the LDS rows base .. base + nb - 1."""
+        which sit in the LDS rows base .. base + nb - 1.  One or two LDS reads per pivot row: lane j
+        of a row of 16 lanes reads the 16-byte pieces j and 16 + j % 4 of the published row, and
+        every multiply-add takes its entry from the lane that holds it (v_fmac_f64 with the DPP
+        control row_newbcast: the first factor comes from a fixed lane of the own row of 16; a
+        broadcast read per pair of entries kept the LDS pipe busy 70 % of the time).  Per element
+        the pivots are applied in ascending order."""
         if not nb:
             return
-        for j in range(1, nb):
-            for h in range((j + 1) // 2):
-                w(f"        const double2 l{tag}_{j}_{h} = pbuf[{((base + j) * ROW_BYTES) // 16 + h}];")
+        npieces = first + (len(trail) + 1) // 2
+        for k in range(nb):
+            w(f"        const double2 q{tag}_{k}_0 = pbuf[{((base + k) * ROW_BYTES) // 16} + rl];")
+            if npieces > 16:
+                w(f"        const double2 q{tag}_{k}_1 = pbuf[{((base + k) * ROW_BYTES) // 16 + 16} + (rl & 3)];")
 
-        def lref(j, k):
-            return f"l{tag}_{j}_{k // 2}.{'xy'[k % 2]}"
+        def fmac(acc, k, t, mult):
+            piece = t // 2
+            w(f'        asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:{piece % 16} row_mask:0xf bank_mask:0xf" : "+v"({acc}) : '
+              f'"v"(q{tag}_{k}_{piece // 16}.{"xy"[t % 2]}), "v"({mult}));')
         for k in range(nb - 2, -1, -1):
             for j in range(k + 1, nb):
-                w("        " + " ".join(f"m{k}_{s} = fma(m{j}_{s}, {lref(j, k)}, m{k}_{s});" for s in slots))
-        tpairs = [trail[i:i + 2] for i in range(0, len(trail), 2)]
-        CH = 2
-        for i0 in range(0, len(tpairs), CH):
-            chunk = list(range(i0, min(i0 + CH, len(tpairs))))
-            for i in chunk:
-                for k in range(nb):
-                    w(f"        const double2 p{tag}_{k}_{i} = pbuf[{((base + k) * ROW_BYTES) // 16 + first + i}];")
-            for i in chunk:
-                for c2, comp in zip(tpairs[i], "xy"):
-                    for s in slots:
-                        for k in range(nb):
-                            w(f"        r{c2}_{s} = fma(m{k}_{s}, p{tag}_{k}_{i}.{comp}, r{c2}_{s});")
+                for s in slots:
+                    fmac(f"m{k}_{s}", j, k, f"m{j}_{s}")
+        for k in range(nb):
+            for i, c2 in enumerate(trail):
+                for s in slots:
+                    fmac(f"r{c2}_{s}", k, 2 * first + i, f"m{k}_{s}")
 
     def emit_joint_block(bi, blk):
         """A block of delayed updates with candidates in both slots: panel steps on the block's own
         columns, then every pivot row's raw trailing entries (and the multipliers it received inside
-        the block) go to LDS in one round of stores, and all rows apply the whole block at once."""
+        the block) go to LDS, and all rows apply the whole block at once.  A row becomes a pivot at
+        most once, so the pivots that sit in slot 0 go out in one round of stores straight from the
+        slot-0 registers and those in slot 1 in a second round: no selection between the slots."""
         cols, trail, nb = blk["cols"], blk["trail"], len(blk["cols"])
         for c in cols + trail:
             need(c, 0)
             need(c, 1)
         w(f"    {{ // stage 2 joint block {bi}: columns {cols}, {len(trail)} trailing columns")
-        w("        int pk = -1, pk2 = -1;            // this lane's first / second pivot inside the block")
-        w("        bool psl = false;                 // slot of the first one")
+        w("        int pk0 = -1, pk1 = -1;           // LDS row (= step inside the block) this lane's slot-0 / slot-1 row is published to")
         for k, c in enumerate(cols):
             w(f"        // step {blk['steps'][k]}: column {c}")
             w(f"        bool sl{k}, none{k};")
@@ -631,20 +617,11 @@ def emit(sched):
             for c2 in cols[k + 1:]:
                 w(f"        {{ const double e = lane_bcast(sl{k} ? r{c2}_1 : r{c2}_0, L{k});")
                 w(f"          r{c2}_0 = fma(m{k}_0, e, r{c2}_0); r{c2}_1 = fma(m{k}_1, e, r{c2}_1); }}")
-            w(f"        {{ const bool me = lane == L{k};")
-            w(f"          pk2 = me && pk >= 0 ? {k} : pk2; psl = me && pk < 0 ? sl{k} : psl; pk = me && pk < 0 ? {k} : pk;")
-            w(f"          act0 = act0 && !(me && !sl{k}); act1 = act1 && !(me && sl{k}); }}")
+            w(f"        {{ const bool me0 = lane == L{k} && !sl{k}, me1 = lane == L{k} && sl{k};")
+            w(f"          pk0 = me0 ? {k} : pk0; pk1 = me1 ? {k} : pk1; act0 = act0 && !me0; act1 = act1 && !me1; }}")
         items, first = row_items(nb, trail)
-
-        def vals(other):
-            a, b = ("0", "1") if other else ("1", "0")
-            return ["0.0" if kind == "z" else f"(psl ? {'mr'[kind == 'r']}{x}_{a} : {'mr'[kind == 'r']}{x}_{b})" for kind, x in items]
-        masked_stores("pa", vals(False), "pk")
-        # a lane whose two rows both became pivots inside this block publishes the second one in a
-        # round of its own; taken only when some lane of the wave needs it
-        w("        if (__builtin_amdgcn_ballot_w64(pk2 >= 0) != 0ull) {")
-        masked_stores("pb", vals(True), "pk2")
-        w("        }")
+        masked_stores_direct("pj0", items, 0, "pk0")
+        masked_stores_direct("pj1", items, 1, "pk1")
         w("        __builtin_amdgcn_wave_barrier();")
         apply_block("j", 0, nb, trail, first, (0, 1))
         w("        __builtin_amdgcn_wave_barrier();")
