@@ -42,6 +42,7 @@ KEEP = list(range(70, 75))          # columns whose rows of Mr are needed
 RHS = list(range(78, 88))
 ROW_BYTES = 320          # LDS bytes per published pivot row of a block (40 doubles); 320 mod 256 = 64 keeps the rows of a block on different banks
 BLOCK = int(os.environ.get("P4PF_ELIM_BLOCK", "4"))      # pivot rows published per block of delayed updates
+PBUF_VEC = ((BLOCK - 1) * (ROW_BYTES // 16) + 32 + 15) // 16 * 16   # 16-byte vectors of LDS scratch per system (the last row is read up to piece 31)
 
 
 def load_template():
@@ -568,7 +569,7 @@ def emit(sched):
         """Effective multipliers m' = m L^-1 (back substitution, L from the heads of the published
         rows) and the update of the trailing columns of `slots` with the block's nb pivot rows,
         which sit in the LDS rows base .. base + nb - 1.  One or two LDS reads per pivot row: lane j
-        of a row of 16 lanes reads the 16-byte pieces j and 16 + j % 4 of the published row, and
+        of a row of 16 lanes reads the 16-byte pieces j and 16 + j of the published row, and
         every multiply-add takes its entry from the lane that holds it (v_fmac_f64 with the DPP
         control row_newbcast: the first factor comes from a fixed lane of the own row of 16; a
         broadcast read per pair of entries kept the LDS pipe busy 70 % of the time).  Per element
@@ -579,7 +580,7 @@ def emit(sched):
         for k in range(nb):
             w(f"        const double2 q{tag}_{k}_0 = pbuf[{((base + k) * ROW_BYTES) // 16} + rl];")
             if npieces > 16:
-                w(f"        const double2 q{tag}_{k}_1 = pbuf[{((base + k) * ROW_BYTES) // 16 + 16} + (rl & 3)];")
+                w(f"        const double2 q{tag}_{k}_1 = pbuf[{((base + k) * ROW_BYTES) // 16 + 16} + rl];")
 
         def fmac(acc, k, t, mult):
             piece = t // 2
@@ -661,7 +662,7 @@ def emit(sched):
     nvec = (max(len(order[0]), len(order[1])) + 15) // 16 + 1     # + 1: the look-ahead fetch of the id vectors
     head = ["// GENERATED by tools/gen_p4pf_elim.py -- do not edit.", "#pragma once", "namespace pose_amd {",
             f"constexpr int ELIM_TAB_VEC = {nvec};   // 16-byte vectors of coefficient ids per (slot, position)",
-            f"constexpr int ELIM_PBUF_VEC = {max(BLOCK, 1) * ROW_BYTES // 16 + 1};   // 16-byte vectors of LDS scratch per system: the published pivot rows of a block, + 1 so that the four systems of a wave sit on different banks",
+            f"constexpr int ELIM_PBUF_VEC = {PBUF_VEC};   // 16-byte vectors of LDS scratch per system: the published pivot rows of a block and the overrun of the readers' second piece; a multiple of 256 bytes, so that the lane groups a ds_read_b128 is served in (lanes 0-3, 12-15 and 20-27 together, ...) see 16 different pieces of 16 bytes when every lane reads piece lane % 16 of its own system's row",
             "// coefficient ids [slot * 16 + position][order of first use] of the initial matrix; 42 = structural zero",
             f"__constant__ __attribute__((aligned(16))) unsigned char c_elim_tab[32 * {nvec * 16}] = {{"]
     for s in (0, 1):
