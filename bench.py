@@ -48,8 +48,8 @@ SCREEN_MFMA_FLOP_PER_PAIR = 96     # what the matrix-core screen executes: three
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--hyps", type=int, default=1 << 20, help="hypotheses per GPU per step")
     ap.add_argument("--matches", type=int, default=4000)
     ap.add_argument("--inlier-frac", type=float, default=0.10)
