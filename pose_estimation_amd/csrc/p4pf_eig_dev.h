@@ -69,21 +69,6 @@ PA_HD void poly_eval2(const double (&c)[N + 1], double x, double &v, double &dv)
     for (int i = N - 1; i >= 0; --i) { dv = fma(dv, x, v); v = fma(v, x, c[i]); }
 }
 
-// Two Newton steps from a point already close to a simple root; a step above 1e-5 relative is
-// not taken.
-template <int N>
-PA_HD double poly_sharpen(const double (&c)[N + 1], double x)
-{
-#pragma unroll
-    for (int it = 0; it < 2; ++it) {
-        double f, df;
-        poly_eval2<N>(c, x, f, df);
-        const double d = f * p4pf_rcp<false>(df);
-        if (fabs(d) <= 1e-5 * fmax(1.0, fabs(x))) x -= d;
-    }
-    return x;
-}
-
 // Iteration budget and relative tolerance of the bracketed root refinement.  Critical points
 // of the derivative chain only delimit brackets and the sextic's roots are polished afterwards
 // on det P(L), so neither needs full precision.
@@ -375,12 +360,6 @@ PA_HD int p4pf_roots_sextic(const double (&a)[50], const p4pf_problem &pb, p4pf_
     double r1[6], r2[6];
     const int n1 = poly_roots<6>::find(q, -1.0, 1.0, r1, P4PF_REFINE_TOL_TOP);
     const int n2 = poly_roots<6>::find(qr, -1.0, 1.0, r2, P4PF_REFINE_TOL_TOP);
-    // Two Newton steps on the sextic itself take a root from the isolation's tolerance to the
-    // accuracy of the deflated coefficients (a dozen multiply-adds each), so that the first
-    // evaluation of det P(L) below usually is the last one; a step that is not small (two roots
-    // about to merge) is not taken.  Done for all twelve entries, used or not: no divergence.
-#pragma unroll
-    for (int i = 0; i < 6; ++i) { r1[i] = poly_sharpen<6>(q, r1[i]); r2[i] = poly_sharpen<6>(qr, r2[i]); }
     int nl = 0;
 #pragma unroll
     for (int i = 0; i < 6; ++i) if (i < n1) { lam[nl < 12 ? nl : 0] = r1[i]; ++nl; }
