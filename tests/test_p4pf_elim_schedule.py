@@ -67,16 +67,22 @@ def test_schedule_reproduces_action_matrix_rows():
 def test_generated_updates_equal_step_by_step_elimination():
     """The kernel skips the stage-1 steps of a slot none of whose rows takes part, eliminates the
     two independent groups of the split phase side by side (per-slot pivots, columns and trailing
-    columns) and takes its pivots in blocks: panel steps on the block's own columns, raw trailing
-    rows of the pivots, effective multipliers m' = m L^-1, one update per block.  Same pivots,
+    columns), gathers the 16 rows that are active after the first joint step in slot 0, and takes
+    its pivots in blocks: panel steps on the block's own columns, raw trailing rows of the
+    pivots, effective multipliers m' = m L^-1, one update per block.  Same pivots,
     same result as the plain row-by-row elimination (up to rounding that scales with the
     conditioning of the sample); blocks cover every step exactly once, a split block publishes at
     most BLOCK rows and no published row exceeds its LDS slot."""
     s = G.build_schedule()
-    sb, jb = G.split_blocks(s, G.BLOCK), G.joint_blocks(s, G.BLOCK)
-    steps = [i for parts in sb for p in parts for i in p["steps"]] + [i for b in jb for i in b["steps"]]
+    sb, jb, gb = G.split_blocks(s, G.BLOCK), G.joint_blocks(s, G.BLOCK), G.single_blocks(s, G.BLOCK)
+    steps = [i for parts in sb + gb for p in parts for i in p["steps"]] + [i for b in jb for i in b["steps"]]
     assert sorted(steps) == list(range(24))
-    for parts in sb:
+    # the rows are gathered in slot 0 after the first joint step: 16 are active then, and every
+    # column one of them can still hold is moved
+    assert G.COMPACT and len(jb) == 1 and len(jb[0]["steps"]) == 1 and not any(parts[1]["steps"] for parts in gb)
+    assert set(G.compact_cols(s)) == set(jb[0]["trail"]) and set(G.KEEP + G.RHS) <= set(G.compact_cols(s))
+    assert len(s["survivors"]) - len(s["split"][0]) - len(s["split"][1]) - 1 == 16
+    for parts in sb + gb:
         assert len(parts[0]["steps"]) + len(parts[1]["steps"]) <= G.BLOCK and parts[1]["base"] == len(parts[0]["steps"])
         for p in parts:
             assert not (set(p["cols"]) & set(p["trail"]))

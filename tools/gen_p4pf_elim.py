@@ -40,8 +40,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CONST = {0: 1.0, 2: -1.0, 3: -1.0, 12: 1.0, 14: -2.0, 22: 1.0, 24: -1.0, 32: 1.0, 34: -1.0}
 KEEP = list(range(70, 75))          # columns whose rows of Mr are needed
 RHS = list(range(78, 88))
-ROW_BYTES = 320          # LDS bytes per published pivot row of a block (40 doubles); 320 mod 256 = 64 keeps the rows of a block on different banks
+ROW_BYTES = 288          # LDS bytes per published pivot row of a block (at most 32 doubles are used); 72 dwords = 8 modulo the 32 banks of a store, so the up to four rows one round of masked stores writes lie on different banks
 BLOCK = int(os.environ.get("P4PF_ELIM_BLOCK", "4"))      # pivot rows published per block of delayed updates
+COMPACT = int(os.environ.get("P4PF_ELIM_COMPACT", "1"))  # after the first joint step the 16 active rows are gathered in slot 0 and the other steps run there alone
 PBUF_VEC = ((BLOCK - 1) * (ROW_BYTES // 16) + 32 + 15) // 16 * 16   # 16-byte vectors of LDS scratch per system (the last row is read up to piece 31)
 
 
@@ -255,9 +256,11 @@ def split_blocks(sched, block):
 
 
 def joint_blocks(sched, block):
-    """Blocks of the joint phase, `block` steps each: steps, own columns, trailing columns."""
+    """Blocks of the joint phase: steps, own columns, trailing columns.  With COMPACT only the
+    first step is taken over both slots (a block of its own): 16 rows are active after it, and
+    they are gathered in slot 0 for the steps that follow (single_blocks)."""
     st2 = sched["stage2"]
-    rest = sched["joint"]
+    rest = sched["joint"][:1] if COMPACT else sched["joint"]
     blocks = []
     for b0 in range(0, len(rest), block):
         idx = rest[b0:b0 + block]
@@ -265,6 +268,27 @@ def joint_blocks(sched, block):
         trail = sorted(set().union(*[set(st2[i]["pattern"]) for i in idx]) - set(cols))
         blocks.append(dict(steps=idx, cols=cols, trail=trail))
     return blocks
+
+
+def single_blocks(sched, block):
+    """With COMPACT: the joint steps after the first, `block` at a time, all rows in slot 0.  Same
+    form as the blocks of the split phase, with nothing for slot 1."""
+    st2 = sched["stage2"]
+    rest = sched["joint"][1:] if COMPACT else []
+    blocks = []
+    for b0 in range(0, len(rest), block):
+        idx = rest[b0:b0 + block]
+        cols = [st2[i]["col"] for i in idx]
+        trail = sorted(set().union(*[set(st2[i]["pattern"]) for i in idx]) - set(cols))
+        blocks.append([dict(steps=idx, cols=cols, trail=trail, base=0), dict(steps=[], cols=[], trail=[], base=len(idx))])
+    return blocks
+
+
+def compact_cols(sched):
+    """Columns a row still holds when the rows are gathered in slot 0."""
+    st2 = sched["stage2"]
+    rest = sched["joint"][1:]
+    return sorted(set().union(*[set(st2[i]["pattern"]) | {st2[i]["col"]} for i in rest]))
 
 
 def row_items(nb, trail):
@@ -409,6 +433,18 @@ def simulate_kernel(sched, k, block=BLOCK):
     for blk in joint_blocks(sched, block):
         if not _block_update(R, active, slot[0] | slot[1], blk["cols"], blk["trail"]):
             return -1, None
+    if COMPACT:
+        # the d-th retired position of slot 0 takes the d-th active row of slot 1
+        dead0 = [p for p in range(16) if not active[p]]
+        act1 = [p for p in range(16, 32) if active[p]]
+        for d, p in enumerate(dead0):
+            if d < len(act1):
+                R[p] = R[act1[d]]
+                active[p] = True
+        active[16:] = False
+        for parts in single_blocks(sched, block):
+            if not _block_update(R, active, slot[0], parts[0]["cols"], parts[0]["trail"]):
+                return -1, None
     return _tail(R, active)
 
 
@@ -424,6 +460,9 @@ def fma_counts(sched, block=BLOCK):
     for blk in joint_blocks(sched, block):
         nb = len(blk["cols"])
         jt += 2 * (nb * len(blk["trail"]) + nb * (nb - 1))
+    for parts in single_blocks(sched, block):
+        nb = len(parts[0]["cols"])
+        jt += nb * len(parts[0]["trail"]) + nb * (nb - 1)
     return dict(stage1=s1, split=sp, joint=jt)
 
 
@@ -632,16 +671,67 @@ def emit(sched):
         emit_split_block(bi, parts)
     for bi, blk in enumerate(joint_blocks(sched, BLOCK)):
         emit_joint_block(bi, blk)
+    if COMPACT:
+        # 29 rows, 13 pivots so far: 16 rows are active, and slot 0 has exactly as many retired
+        # positions as slot 1 has active rows.  The d-th retired position of slot 0 takes the d-th
+        # active row of slot 1; the remaining steps then run in slot 0 alone: half the multiply-adds,
+        # one round of stores per block, no selection between the slots.
+        cc = compact_cols(sched)
+        for c in cc:
+            need(c, 0)
+            need(c, 1)
+        nmove = 16 - sum(1 for r in sched["survivors"] if sched["slot_of"][r] == 0) + len(sched["split"][0]) + 1
+        gstride = len(cc) * 8 + 8           # bytes between the moved rows in LDS: not a multiple of 256, so that the rows sit on different banks
+        assert nmove * gstride <= PBUF_VEC * 16
+        w("    { // gather the active rows in slot 0: through LDS, stores and loads under EXEC masks, no selects")
+        w("        const unsigned a1m = (unsigned)(__ballot(act1) >> sh) & 0xffffu;      // active rows of slot 1, this system")
+        w("        const unsigned d0m = ~(unsigned)(__ballot(act0) >> sh) & 0xffffu;     // retired positions of slot 0")
+        w("        const unsigned below = (1u << rl) - 1u;")
+        w("        const int j1 = __popc(a1m & below), d = __popc(d0m & below);           // rank of this lane's slot-1 row / slot-0 position")
+        w(f"        const bool give = act1 && j1 < {nmove}, take = !act0 && d < __popc(a1m) && d < {nmove};")
+        w("        const unsigned long long gm = __builtin_amdgcn_ballot_w64(give), tm = __builtin_amdgcn_ballot_w64(take);")
+        w(f"        const unsigned gaddr = pbuf_addr + (unsigned)(give ? j1 : 0) * {gstride}u, taddr = pbuf_addr + (unsigned)(take ? d : 0) * {gstride}u;")
+        for g0 in range(0, len(cc), 12):
+            grp = cc[g0:g0 + 12]
+            lines = ['"s_mov_b64 exec, %[mask]\\n\\t"']
+            for j in range(0, len(grp), 2):
+                if j + 1 < len(grp):
+                    lines.append(f'"ds_write2_b64 %[addr], %[a{j}], %[a{j + 1}] offset0:{g0 + j} offset1:{g0 + j + 1}\\n\\t"')
+                else:
+                    lines.append(f'"ds_write_b64 %[addr], %[a{j}] offset:{8 * (g0 + j)}\\n\\t"')
+            lines.append('"s_mov_b64 exec, -1"')
+            w("        asm volatile(" + "\n                     ".join(lines))
+            ops = ", ".join(f'[a{j}] "v"(r{c}_1)' for j, c in enumerate(grp))
+            w(f'                     :: [mask] "s"(gm), [addr] "v"(gaddr), {ops} : "memory");')
+        # the loads land in the registers of the positions that take a row; every other lane keeps
+        # what it has.  LDS operations of a wave execute in order, so the loads see the stores; the
+        # wait for the loaded values is part of the statement (the compiler does not know of them).
+        for g0 in range(0, len(cc), 14):
+            grp = cc[g0:g0 + 14]
+            lines = ['"s_mov_b64 exec, %[mask]\\n\\t"']
+            for j, c in enumerate(grp):
+                lines.append(f'"ds_read_b64 %[a{j}], %[addr] offset:{8 * (g0 + j)}\\n\\t"')
+            lines.append('"s_waitcnt lgkmcnt(0)\\n\\t"')
+            lines.append('"s_mov_b64 exec, -1"')
+            w("        asm volatile(" + "\n                     ".join(lines))
+            ops = ", ".join(f'[a{j}] "+v"(r{c}_0)' for j, c in enumerate(grp))
+            w(f'                     : {ops} : [mask] "s"(tm), [addr] "v"(taddr) : "memory");')
+        w("        act0 = act0 || take; act1 = false;")
+        w("        __builtin_amdgcn_wave_barrier();")
+        w("    }")
+        for bi, parts in enumerate(single_blocks(sched, BLOCK)):
+            emit_split_block(100 + bi, parts)
     for c in KEEP + RHS:
         need(c, 0)
-        need(c, 1)
+        if not COMPACT:
+            need(c, 1)
     w("    {")
     w("        const unsigned a0 = (unsigned)(__ballot(act0) >> sh) & 0xffffu, a1 = (unsigned)(__ballot(act1) >> sh) & 0xffffu;")
     w("        const int n0 = __popc(a0);")
     w("        bad |= n0 + __popc(a1) != 5;")
     w("        const unsigned below = (1u << rl) - 1u;")
-    w("        const int rank0 = __popc(a0 & below), rank1 = n0 + __popc(a1 & below);")
-    for s in (0, 1):
+    w("        [[maybe_unused]] const int rank0 = __popc(a0 & below), rank1 = n0 + __popc(a1 & below);")
+    for s in ((0,) if COMPACT else (0, 1)):
         w(f"        if (wr && act{s} && rank{s} < 5) {{")
         w(f"            double *o = tail5x15 + (size_t)(rank{s} * 15) * stride;")
         for j, c in enumerate(KEEP + RHS):
