@@ -386,10 +386,10 @@ __device__ __forceinline__ void p4pf_elim_block(const query_dev &q, uint32_t hyp
 {
     __shared__ double cf[ELIM_BATCH][43];
     __shared__ int st_s[ELIM_BATCH];
-    __shared__ uint4 tab[32 * ELIM_TAB_VEC];
+    __shared__ uint4 tab[32 * ELIM_TAB_VEC + 1];
     __shared__ __attribute__((aligned(256))) double2 pbuf[4][ELIM_PBUF_VEC];   // per row of 16 lanes: the published pivot rows of a block (the four systems on the same banks: see ELIM_PBUF_VEC)
     const int lane = threadIdx.x;
-    for (int i = lane; i < 32 * ELIM_TAB_VEC; i += 64) tab[i] = reinterpret_cast<const uint4 *>(c_elim_tab)[i];
+    for (int i = lane; i < 32 * ELIM_TAB_VEC + 1; i += 64) tab[i] = reinterpret_cast<const uint4 *>(c_elim_tab)[i];
     const uint32_t nbatch = (hyp_count + batch - 1) / batch;
     for (uint32_t b = bx; b < nbatch; b += gx) {
         if (lane < batch) {

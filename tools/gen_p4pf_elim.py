@@ -749,17 +749,23 @@ def emit(sched):
     # a register that was never created must not hide an entry of the initial matrix
     for r in sched["lanes_rows"]:
         assert set(sched["orig"][r]) <= set(order[sched["slot_of"][r]]), "an initial entry has no register"
-    nvec = (max(len(order[0]), len(order[1])) + 15) // 16 + 1     # + 1: the look-ahead fetch of the id vectors
+    # 16-byte vectors per position.  An odd number: the 16 positions of a slot then start on 16 different
+    # groups of four banks, which is what the lane groups of a ds_read_b128 need.  The look-ahead fetch
+    # of a position's last vector reads the first one of the next position (one vector of padding
+    # at the end of the table).
+    nvec = (max(len(order[0]), len(order[1])) + 15) // 16
+    nvec += 1 - nvec % 2
     head = ["// GENERATED by tools/gen_p4pf_elim.py -- do not edit.", "#pragma once", "namespace pose_amd {",
             f"constexpr int ELIM_TAB_VEC = {nvec};   // 16-byte vectors of coefficient ids per (slot, position)",
             f"constexpr int ELIM_PBUF_VEC = {PBUF_VEC};   // 16-byte vectors of LDS scratch per system: the published pivot rows of a block and the overrun of the readers' second piece; a multiple of 256 bytes, so that the lane groups a ds_read_b128 is served in (lanes 0-3, 12-15 and 20-27 together, ...) see 16 different pieces of 16 bytes when every lane reads piece lane % 16 of its own system's row",
             "// coefficient ids [slot * 16 + position][order of first use] of the initial matrix; 42 = structural zero",
-            f"__constant__ __attribute__((aligned(16))) unsigned char c_elim_tab[32 * {nvec * 16}] = {{"]
+            f"__constant__ __attribute__((aligned(16))) unsigned char c_elim_tab[32 * {nvec * 16} + 16] = {{"]
     for s in (0, 1):
         for pos in range(16):
             ids = [int(tbl[16 * s + pos, c]) for c in order[s]]
             ids += [42] * (nvec * 16 - len(ids))
             head.append("  " + ",".join(str(v) for v in ids) + ",")
+    head.append("  " + ",".join(["42"] * 16))
     head.append("};")
     return "\n".join(head + o) + "\n"
 
