@@ -295,13 +295,15 @@ __global__ __launch_bounds__(256) void k_seg_coverage(seg_launch L, seg_cov C, i
 constexpr int CVP_THREADS = CVP_T;       // threads per block
 constexpr int CVP_KM = 6144 / CVP_THREADS;   // correspondences per thread
 constexpr int CVP_BIAS = 16384;          // keypoint coordinates are stored as 16-bit values with this bias
+constexpr int CVP_SMALL = 32;            // poses with at most this many inliers get their area without the bitmap
 constexpr int CVP_PASSES = 16;           // passes a query may need (more: the query's areas come from k_seg_coverage)
 
 __global__ __launch_bounds__(CVP_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_seg_cover_pose(seg_launch L, seg_cov C, int which, const double *__restrict__ proj, double eps)
 {
     extern __shared__ unsigned long long s_rows[];
     __shared__ unsigned long long s_red[CVP_THREADS / 64];
-    __shared__ int s_any;
+    __shared__ unsigned long long s_small[CVP_SMALL], s_sorted[CVP_SMALL];   // the boxes of a pose with few inliers (sx | ex << 16 | sy << 32 | ey << 48)
+    __shared__ int s_any, s_small_n;
     const int a = blockIdx.z;
     if (!seg_live(L, a)) return;
     const seg_query &sq = seg_of(L, a);
@@ -362,6 +364,69 @@ __global__ __launch_bounds__(CVP_THREADS) __attribute__((amdgpu_waves_per_eu(4, 
             const double rx = fma(u, pz, -px), ry = fma(v, pz, -py);
             const double te = eps * pz;
             if (rxy[k] != 0xFFFFFFFFu && fma(ry, ry, rx * rx) < te * te) inl |= 1u << k;     // rxy is ~0 beyond n as well
+        }
+        // ---- few inliers (nearly every pose the basic sampler's loop asks about: chance poses with a
+        // handful of inliers): the area of the union of their boxes directly, by one wave.  The boxes
+        // are listed in LDS; lane l takes the horizontal strip that starts at the l-th of the 2K lower /
+        // upper box edges and ends at the next edge above it, and sweeps the boxes that cover the strip in
+        // order of their left ends.  Integer arithmetic throughout: the same area as the bitmap gives.
+        __syncthreads();                                     // the previous pose is done with the list
+        if (tid == 0) s_small_n = 0;
+        __syncthreads();
+        {
+            const int mine = __popc(inl);
+            int at = mine ? atomicAdd(&s_small_n, mine) : 0;
+            if (mine && at + mine <= CVP_SMALL) {
+#pragma unroll
+                for (int k = 0; k < CVP_KM; ++k) {
+                    if (!((inl >> k) & 1u)) continue;
+                    const int x = (int)(rxy[k] & 0xFFFFu) - CVP_BIAS, y = (int)(rxy[k] >> 16) - CVP_BIAS;
+                    const unsigned long long sx = (unsigned)max(0, min(x - h, q.width - 1)), ex = (unsigned)max(0, min(x + h, q.width - 1));
+                    const unsigned long long sy = (unsigned)max(0, min(y - h, q.height - 1)), ey = (unsigned)max(0, min(y + h, q.height - 1));
+                    s_small[at++] = sx | (ex << 16) | (sy << 32) | (ey << 48);
+                }
+            }
+        }
+        __syncthreads();
+        const int K = s_small_n;                             // block-uniform
+        if (K <= CVP_SMALL) {
+            if (tid < 64) {
+                // the boxes in order of their left ends (rank by counting; ties by position in the list)
+                const unsigned long long mybox = s_small[lane < K ? lane : 0];
+                const int mysx = (int)(mybox & 0xffffu);
+                int rank = 0;
+                for (int j = 0; j < K; ++j) {
+                    const int sxj = (int)(s_small[j] & 0xffffu);
+                    rank += (sxj < mysx || (sxj == mysx && j < lane)) ? 1 : 0;
+                }
+                if (lane < K) s_sorted[rank] = mybox;
+                __builtin_amdgcn_wave_barrier();
+                // this lane's edge: lower edges of the boxes first, then the upper ones
+                const bool lv = lane < 2 * K;
+                const int b = lv ? (int)((s_small[lane < K ? lane : lane - K] >> (lane < K ? 32 : 48)) & 0xffffu) : 0x7fffffff;
+                int nxt = 0x7fffffff;
+                bool dup = false;                            // an earlier lane has the same edge: it takes the strip
+                for (int m = 0; m < 2 * K; ++m) {
+                    const int bm = (int)((s_small[m < K ? m : m - K] >> (m < K ? 32 : 48)) & 0xffffu);
+                    if (bm > b) nxt = min(nxt, bm);
+                    dup = dup || (bm == b && m < lane);
+                }
+                int tot = 0, cur = 0;                        // covered columns of the strip so far, right end of the cover
+                for (int j = 0; j < K; ++j) {
+                    const unsigned long long r = s_sorted[j];
+                    const int sxj = (int)(r & 0xffffu), exj = (int)((r >> 16) & 0xffffu), syj = (int)((r >> 32) & 0xffffu), eyj = (int)(r >> 48);
+                    const bool cover = syj <= b && eyj > b;
+                    const int add = max(exj - max(sxj, cur), 0);
+                    tot += cover ? add : 0;
+                    cur = cover ? max(cur, exj) : cur;
+                }
+                unsigned long long part = (lv && !dup && nxt != 0x7fffffff) ? (unsigned long long)(nxt - b) * (unsigned long long)tot : 0ull;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
+                if (tid == 0) sums[(size_t)pose * sq.bands + blockIdx.y] = blockIdx.y == 0 ? part : 0ull;
+            }
+            if (blockIdx.y == 0) for (int b2 = ny + tid; b2 < sq.bands; b2 += CVP_THREADS) sums[(size_t)pose * sq.bands + b2] = 0ull;
+            continue;
         }
         unsigned long long area = 0;
         for (int row0 = (int)blockIdx.y * RB, pass = (int)blockIdx.y; row0 < q.height; row0 += ny * RB, pass += ny) {
