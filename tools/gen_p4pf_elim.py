@@ -21,7 +21,10 @@ p = 16 * slot + lane % 16; one named register per (column, slot)):
            so the two groups are eliminated side by side: every slot searches its own pivot,
            publishes from its own registers (no selection between the slots) and updates only
            its own rows, over its own set of trailing columns.
-           joint phase: the last 12 columns, candidates in both slots.
+           joint phase: the last 12 columns have candidates in both slots.  The first of them is
+           eliminated over both slots; 16 rows are active after it, slot 0 then has as many retired
+           positions as slot 1 has active rows, the latter move into the former (through LDS, under
+           EXEC masks) and the other 11 columns are eliminated in slot 0 alone.
   tail     the 5 rows left over hold a 5 x 15 system in columns 70..74 | 78..87; it is written
            out and solved per lane by the consumer (p4pf_reduce_tail), where it costs no
            cross-lane traffic.
