@@ -46,7 +46,7 @@ RHS = list(range(78, 88))
 ROW_BYTES = 288          # LDS bytes per published pivot row of a block (at most 32 doubles are used); 72 dwords = 8 modulo the 32 banks of a store, so the up to four rows one round of masked stores writes lie on different banks
 BLOCK = int(os.environ.get("P4PF_ELIM_BLOCK", "4"))      # pivot rows published per block of delayed updates
 COMPACT = int(os.environ.get("P4PF_ELIM_COMPACT", "1"))  # after the first joint step the 16 active rows are gathered in slot 0 and the other steps run there alone
-PBUF_VEC = ((BLOCK - 1) * (ROW_BYTES // 16) + 32 + 15) // 16 * 16   # 16-byte vectors of LDS scratch per system (the last row is read up to piece 31)
+PBUF_VEC = 96            # 16-byte vectors of LDS scratch per system; every read of a published row is checked against it
 
 
 def load_template():
@@ -230,31 +230,44 @@ def build_schedule():
 
 
 def split_blocks(sched, block):
-    """Blocks of the split phase: each takes the next steps of both slots, `block` pivot rows in
-    all (they share the block's LDS rows), shared out in proportion to what the slots have left.
+    """Blocks of the split phase.  Every block serves ONE slot: each round of masked stores costs
+    the same whatever the number of rows it publishes (2 + 2, 2 + 2, 1 + 3 pivots in three blocks
+    are six rounds and measured 7 % slower than three blocks of one slot each), so a slot's steps
+    are cut into as few, nearly equal blocks as the scratch allows (a row of more than 32 doubles
+    takes a second read that reaches further) and the blocks of the two slots alternate.
     Per block and slot: step indices, own columns, trailing columns (every column one of the slot's
-    pivot rows of the block can hold, minus the slot-block's own), first LDS row."""
+    pivot rows of the block can hold, minus the block's own), first LDS row."""
     st2 = sched["stage2"]
-    left = [list(sched["split"][0]), list(sched["split"][1])]
+
+    def part(idx, base):
+        cols = [st2[i]["col"] for i in idx]
+        trail = sorted(set().union(*[set(st2[i]["pattern"]) for i in idx]) - set(cols)) if idx else []
+        return dict(steps=idx, cols=cols, trail=trail, base=base)
+
+    def fits(idx):
+        p = part(idx, 0)
+        nb = len(idx)
+        n_items = 2 * ((nb - 1 + 1) // 2) + len(p["trail"])
+        return n_items * 8 <= ROW_BYTES and ((nb - 1) * ROW_BYTES) // 16 + (32 if n_items > 32 else 16) <= PBUF_VEC
+
+    chunks = []
+    for s in (0, 1):
+        steps = list(sched["split"][s])
+        n = 1
+        while True:                               # fewest chunks, sizes as equal as possible, the smaller ones first
+            sizes = [len(steps) // n + (1 if i >= n - len(steps) % n else 0) for i in range(n)]
+            cut = [steps[sum(sizes[:i]):sum(sizes[:i + 1])] for i in range(n)]
+            if all(fits(c) for c in cut):
+                break
+            n += 1
+        chunks.append(cut)
+    first = 0 if len(chunks[0]) > len(chunks[1]) else 1
     blocks = []
-    while left[0] or left[1]:
-        tot = len(left[0]) + len(left[1])
-        n0 = min(len(left[0]), max(1 if left[0] else 0, (block * len(left[0]) + tot // 2) // tot))
-        n1 = min(len(left[1]), block - n0)
-        if n1 == 0 and left[1]:
-            n0, n1 = n0 - 1, 1
-        n0 = min(len(left[0]), block - n1)
-        take = (left[0][:n0], left[1][:n1])
-        left = [left[0][n0:], left[1][n1:]]
-        parts = []
-        base = 0
-        for s in (0, 1):
-            idx = take[s]
-            cols = [st2[i]["col"] for i in idx]
-            trail = sorted(set().union(*[set(st2[i]["pattern"]) for i in idx]) - set(cols)) if idx else []
-            parts.append(dict(steps=idx, cols=cols, trail=trail, base=base))
-            base += len(idx)
-        blocks.append(parts)
+    while chunks[0] or chunks[1]:
+        for s in (first, 1 - first):
+            if chunks[s]:
+                idx = chunks[s].pop(0)
+                blocks.append([part(idx, 0) if t == s else part([], len(idx) if t == 1 else 0) for t in (0, 1)])
     return blocks
 
 
@@ -619,6 +632,7 @@ def emit(sched):
         if not nb:
             return
         npieces = first + (len(trail) + 1) // 2
+        assert ((base + nb - 1) * ROW_BYTES) // 16 + (32 if npieces > 16 else 16) <= PBUF_VEC, "a reader of the block's last row would leave the scratch"
         for k in range(nb):
             w(f"        const double2 q{tag}_{k}_0 = pbuf[{((base + k) * ROW_BYTES) // 16} + rl];")
             if npieces > 16:
