@@ -358,7 +358,7 @@ __device__ __forceinline__ void gather_p4pf(const query_dev &q, const uint4 s, d
 // sample tuples or, for the batch entry point, from explicit m2d / M3D arrays.
 // ------------------------------------------------------------------------------------------
 #ifndef POSE_AMD_ELIM_BATCH
-#define POSE_AMD_ELIM_BATCH 32
+#define POSE_AMD_ELIM_BATCH 28
 #endif
 constexpr int ELIM_BATCH = POSE_AMD_ELIM_BATCH;     // systems per block and round at most; the launch passes a `batch` <= this that is a multiple of 4
                                    // (small launches use small batches so that they still fill the chip)

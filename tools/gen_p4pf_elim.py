@@ -43,10 +43,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CONST = {0: 1.0, 2: -1.0, 3: -1.0, 12: 1.0, 14: -2.0, 22: 1.0, 24: -1.0, 32: 1.0, 34: -1.0}
 KEEP = list(range(70, 75))          # columns whose rows of Mr are needed
 RHS = list(range(78, 88))
-ROW_BYTES = 288          # LDS bytes per published pivot row of a block (at most 32 doubles are used); 72 dwords = 8 modulo the 32 banks of a store, so the up to four rows one round of masked stores writes lie on different banks
+ROW_BYTES = 272          # LDS bytes per published pivot row of a block (at most 34 doubles are used); 68 dwords = 4 modulo the 32 banks of a store, so the up to six rows one round of masked stores writes lie on different banks
 BLOCK = int(os.environ.get("P4PF_ELIM_BLOCK", "4"))      # pivot rows published per block of delayed updates
 COMPACT = int(os.environ.get("P4PF_ELIM_COMPACT", "1"))  # after the first joint step the 16 active rows are gathered in slot 0 and the other steps run there alone
-PBUF_VEC = 96            # 16-byte vectors of LDS scratch per system; every read of a published row is checked against it
+PBUF_VEC = 112           # 16-byte vectors of LDS scratch per system; every read of a published row is checked against it
 
 
 def load_template():
@@ -229,6 +229,26 @@ def build_schedule():
     return _build_schedule([(greedy[i]["row"], greedy[i]["col"]) for i in STAGE1_ORDER])
 
 
+def _chunks(steps, fits):
+    """steps cut into the fewest runs that all fit, sizes as equal as possible, the smaller ones first."""
+    n = 1
+    while True:
+        sizes = [len(steps) // n + (1 if i >= n - len(steps) % n else 0) for i in range(n)]
+        cut = [steps[sum(sizes[:i]):sum(sizes[:i + 1])] for i in range(n)]
+        if all(fits(c) for c in cut):
+            return cut
+        n += 1
+
+
+def _fits(st2, idx):
+    """Whether the pivot rows of the steps idx (one slot) fit the LDS scratch as one block."""
+    cols = [st2[i]["col"] for i in idx]
+    trail = set().union(*[set(st2[i]["pattern"]) for i in idx]) - set(cols)
+    nb = len(idx)
+    n_items = 2 * ((nb - 1 + 1) // 2) + len(trail)
+    return n_items * 8 <= ROW_BYTES and ((nb - 1) * ROW_BYTES) // 16 + (32 if n_items > 32 else 16) <= PBUF_VEC
+
+
 def split_blocks(sched, block):
     """Blocks of the split phase.  Every block serves ONE slot: each round of masked stores costs
     the same whatever the number of rows it publishes (2 + 2, 2 + 2, 1 + 3 pivots in three blocks
@@ -245,22 +265,9 @@ def split_blocks(sched, block):
         return dict(steps=idx, cols=cols, trail=trail, base=base)
 
     def fits(idx):
-        p = part(idx, 0)
-        nb = len(idx)
-        n_items = 2 * ((nb - 1 + 1) // 2) + len(p["trail"])
-        return n_items * 8 <= ROW_BYTES and ((nb - 1) * ROW_BYTES) // 16 + (32 if n_items > 32 else 16) <= PBUF_VEC
+        return _fits(st2, idx)
 
-    chunks = []
-    for s in (0, 1):
-        steps = list(sched["split"][s])
-        n = 1
-        while True:                               # fewest chunks, sizes as equal as possible, the smaller ones first
-            sizes = [len(steps) // n + (1 if i >= n - len(steps) % n else 0) for i in range(n)]
-            cut = [steps[sum(sizes[:i]):sum(sizes[:i + 1])] for i in range(n)]
-            if all(fits(c) for c in cut):
-                break
-            n += 1
-        chunks.append(cut)
+    chunks = [_chunks(list(sched["split"][s]), fits) for s in (0, 1)]
     first = 0 if len(chunks[0]) > len(chunks[1]) else 1
     blocks = []
     while chunks[0] or chunks[1]:
@@ -292,8 +299,7 @@ def single_blocks(sched, block):
     st2 = sched["stage2"]
     rest = sched["joint"][1:] if COMPACT else []
     blocks = []
-    for b0 in range(0, len(rest), block):
-        idx = rest[b0:b0 + block]
+    for idx in (_chunks(list(rest), lambda c: _fits(st2, c)) if rest else []):
         cols = [st2[i]["col"] for i in idx]
         trail = sorted(set().union(*[set(st2[i]["pattern"]) for i in idx]) - set(cols))
         blocks.append([dict(steps=idx, cols=cols, trail=trail, base=0), dict(steps=[], cols=[], trail=[], base=len(idx))])
