@@ -683,8 +683,17 @@ def emit(sched):
             w(f"        {{ const bool me0 = lane == L{k} && !sl{k}, me1 = lane == L{k} && sl{k};")
             w(f"          pk0 = me0 ? {k} : pk0; pk1 = me1 ? {k} : pk1; act0 = act0 && !me0; act1 = act1 && !me1; }}")
         items, first = row_items(nb, trail)
-        masked_stores_direct("pj0", items, 0, "pk0")
-        masked_stores_direct("pj1", items, 1, "pk1")
+        if nb == 1:
+            # one pivot row per system: the slot it sits in is chosen with selects (two per double) and
+            # the row goes out in ONE round of stores -- a round costs more than the selects
+            for kind, x in items:
+                if kind == "r":
+                    w(f"        const double rsel{x}_0 = sl0 ? r{x}_1 : r{x}_0;")
+            w("        const int pks = lane == L0 ? 0 : -1;")
+            masked_stores_direct("pjs", [(kind, f"sel{x}") if kind == "r" else (kind, x) for kind, x in items], 0, "pks")
+        else:
+            masked_stores_direct("pj0", items, 0, "pk0")
+            masked_stores_direct("pj1", items, 1, "pk1")
         w("        __builtin_amdgcn_wave_barrier();")
         apply_block("j", 0, nb, trail, first, (0, 1))
         w("        __builtin_amdgcn_wave_barrier();")
