@@ -59,3 +59,21 @@ def reduce_best(key, dist=None, device="cpu"):
     t = torch.tensor([int(key)], dtype=torch.int64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return int(t.item())
+
+
+def reduce_best_begin(key, dist=None, device="cpu"):
+    """The same reduction started without waiting for it: the collective runs beside the next
+    step's kernels (the library computes on a stream of its own).  -> handle for reduce_best_end."""
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return (None, int(key))
+    import torch
+    t = torch.tensor([int(key)], dtype=torch.int64, device=device)
+    return (dist.all_reduce(t, op=dist.ReduceOp.MAX, async_op=True), t)
+
+
+def reduce_best_end(handle):
+    work, t = handle
+    if work is None:
+        return t
+    work.wait()
+    return int(t.item())

@@ -28,6 +28,9 @@ def main():
     r = O.ransac(*args, samples, select_coverage=False, early_exit=False, max_steps=len(samples))
     key = shard.pack_key(r["hyposet"], begin + r["best_step"]) if r["found"] else 0
     best = shard.reduce_best(key, dist)
+    # the same reduction started without waiting, several in flight (what bench.py does per step)
+    handles = [shard.reduce_best_begin(key + i, dist) for i in range(3)]
+    best_async = [shard.reduce_best_end(h) for h in handles]
     # by-query partition: every query is owned by exactly one rank
     costs = [4000 + 37 * i % 2000 for i in range(50)]
     mine = shard.query_shard(costs, rank, world)
@@ -41,7 +44,8 @@ def main():
         loads = [sum(costs[i] for i in part) for part in gathered]
         with open(out_path, "w") as f:
             json.dump({"world": world, "count": count, "hyp": hyp, "ref_count": int(ref["hyposet"]), "ref_hyp": int(ref["best_step"]),
-                       "queries_ok": flat == list(range(50)), "loads": loads}, f)
+                       "queries_ok": flat == list(range(50)), "loads": loads,
+                       "async_ok": best_async == [best + i for i in range(3)]}, f)
     dist.barrier()
     dist.destroy_process_group()
 
