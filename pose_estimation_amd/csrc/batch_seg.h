@@ -509,7 +509,7 @@ __global__ __launch_bounds__(CVP_THREADS) __attribute__((amdgpu_waves_per_eu(4, 
                 if (c >= W) { c -= W; ++k; }
             }
             // The painted rows go back to zero by wiping exactly the words that were painted: work in
-            // proportion to the inliers, where clearing the whole bitmap (60 KB per pass) was a fifth of
+            // proportion to the inliers, where clearing the whole bitmap (60 to 76 KB per pass) was a fifth of
             // the kernel's time.  The group unions need no clearing: every word of them that a pass
             // reads it has written before.
             __syncthreads();                                 // everybody has read the rows

@@ -1312,9 +1312,11 @@ static int batch_fill(pose_amd_ctx *ctx, pose_amd_batch *b, int nq, const pose_a
                 sq.box = (long long)(2 * (cover / 2)) * (2 * (cover / 2));
                 size_t lds = 0;
                 if (!coverage_geometry(q.width, q.height, sq.band_rows, sq.bands, sq.wpr, sq.separable, lds)) { bad_geometry = 1; continue; }
-                {   // one block per pose where the query fits it: rows per pass from 60 KB of LDS
+                {   // one block per pose where the query fits it: rows per pass from 76 KB of LDS, the most that leaves
+                    // two blocks on a compute unit (fewer, taller passes: 60 KB measured 5 % slower for the advanced batch)
                     const int W = (q.width + 63) / 64, h2 = 2 * ((int)std::ceil((float)q.width / 20.0f) / 2);
-                    const int rows_total = (60 * 1024) / (8 * W);
+                    static const int cover_kb = getenv("POSE_AMD_SEG_COVER_KB") ? std::max(16, std::min(150, atoi(getenv("POSE_AMD_SEG_COVER_KB")))) : 76;
+                    const int rows_total = (cover_kb * 1024) / (8 * W);
                     const int nhp = (rows_total * 8 / 9) & ~7;
                     int rb = (nhp - 8 - (h2 - 1)) & ~7;
                     rb = std::min(rb, (q.height + 7) & ~7);
