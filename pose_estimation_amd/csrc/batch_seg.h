@@ -303,11 +303,13 @@ __global__ __launch_bounds__(CVP_THREADS) __attribute__((amdgpu_waves_per_eu(4, 
     extern __shared__ unsigned long long s_rows[];
     __shared__ unsigned long long s_red[CVP_THREADS / 64];
     __shared__ unsigned long long s_small[CVP_SMALL], s_sorted[CVP_SMALL];   // the boxes of a pose with few inliers (sx | ex << 16 | sy << 32 | ey << 48)
-    __shared__ int s_any, s_small_n;
+    __shared__ int s_any, s_small_n[2];
     const int a = blockIdx.z;
     if (!seg_live(L, a)) return;
     const seg_query &sq = seg_of(L, a);
     if (!sq.cv_rows) return;
+    int tok = 0, pp = 0;                                     // block-uniform: pass counter, counter in use
+    if (threadIdx.x == 0) { s_any = 0; s_small_n[0] = s_small_n[1] = 0; }   // ordered before their first use by the first pose's barrier
     const int cap = which ? C.cap2 : C.cap1;
     const int n = min(C.n[4 * a + which], cap);
     // blockIdx.y: the block's share of the passes (pass y, y + ny, ...); its sum goes into band y of the pose's sums
@@ -351,31 +353,49 @@ __global__ __launch_bounds__(CVP_THREADS) __attribute__((amdgpu_waves_per_eu(4, 
         load_pose_uniform(pq, __builtin_amdgcn_readfirstlane(list[pose]), P);
         // ---- the pose's inliers among the thread's correspondences --------------------------------
         unsigned inl = 0;
+        {
+            // The array pointers and the count are read from the query's descriptor ONCE per pose, in front
+            // of the loop: read where they are used, inside the conditional blocks of the unrolled loop,
+            // they were loaded again for every correspondence -- pointer load, wait, data load, wait,
+            // twelve times per pose, 60 % of the kernel's time.  Four correspondences at a time: their
+            // twenty loads are in flight together.
+            const float *kxp = sq.skx, *kyp = sq.sky, *Xp = sq.sX, *Yp = sq.sY, *Zp = sq.sZ;
+            const int qn = q.n;
 #pragma unroll
-        for (int k = 0; k < CVP_KM; ++k) {
-            if (k * CVP_THREADS >= q.n) break;                       // block-uniform
-            const int i = min(tid + k * CVP_THREADS, q.n - 1);       // loads without a branch in front of them
-            const float kxf = sq.skx[i], kyf = sq.sky[i];
-            const double X = sq.sX[i], Y = sq.sY[i], Z = sq.sZ[i];
-            const double u = -((double)kxf - hw), v = -((double)kyf - hh);
-            const double px = fma(P[0], X, fma(P[1], Y, fma(P[2], Z, P[3])));
-            const double py = fma(P[4], X, fma(P[5], Y, fma(P[6], Z, P[7])));
-            const double pz = fma(P[8], X, fma(P[9], Y, fma(P[10], Z, P[11])));
-            const double rx = fma(u, pz, -px), ry = fma(v, pz, -py);
-            const double te = eps * pz;
-            if (rxy[k] != 0xFFFFFFFFu && fma(ry, ry, rx * rx) < te * te) inl |= 1u << k;     // rxy is ~0 beyond n as well
+            for (int k0 = 0; k0 < CVP_KM; k0 += 4) {
+                if (k0 * CVP_THREADS >= qn) break;                       // block-uniform
+                float kxf[4], kyf[4], Xf[4], Yf[4], Zf[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int i = min(tid + (k0 + j) * CVP_THREADS, qn - 1);   // loads without a branch in front of them
+                    kxf[j] = kxp[i]; kyf[j] = kyp[i]; Xf[j] = Xp[i]; Yf[j] = Yp[i]; Zf[j] = Zp[i];
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int k = k0 + j;
+                    const double X = Xf[j], Y = Yf[j], Z = Zf[j];
+                    const double u = -((double)kxf[j] - hw), v = -((double)kyf[j] - hh);
+                    const double px = fma(P[0], X, fma(P[1], Y, fma(P[2], Z, P[3])));
+                    const double py = fma(P[4], X, fma(P[5], Y, fma(P[6], Z, P[7])));
+                    const double pz = fma(P[8], X, fma(P[9], Y, fma(P[10], Z, P[11])));
+                    const double rx = fma(u, pz, -px), ry = fma(v, pz, -py);
+                    const double te = eps * pz;
+                    if (rxy[k] != 0xFFFFFFFFu && fma(ry, ry, rx * rx) < te * te) inl |= 1u << k;     // rxy is ~0 beyond n as well
+                }
+            }
         }
         // ---- few inliers (nearly every pose the basic sampler's loop asks about: chance poses with a
         // handful of inliers): the area of the union of their boxes directly, by one wave.  The boxes
         // are listed in LDS; lane l takes the horizontal strip that starts at the l-th of the 2K lower /
         // upper box edges and ends at the next edge above it, and sweeps the boxes that cover the strip in
         // order of their left ends.  Integer arithmetic throughout: the same area as the bitmap gives.
+        // Two counters used in turn, so that the one of the next pose can be zeroed without a barrier of
+        // its own (every barrier of this kernel is eight waves waiting for the slowest one).
+        pp ^= 1;
         __syncthreads();                                     // the previous pose is done with the list
-        if (tid == 0) s_small_n = 0;
-        __syncthreads();
         {
             const int mine = __popc(inl);
-            int at = mine ? atomicAdd(&s_small_n, mine) : 0;
+            int at = mine ? atomicAdd(&s_small_n[pp], mine) : 0;
             if (mine && at + mine <= CVP_SMALL) {
 #pragma unroll
                 for (int k = 0; k < CVP_KM; ++k) {
@@ -388,7 +408,8 @@ __global__ __launch_bounds__(CVP_THREADS) __attribute__((amdgpu_waves_per_eu(4, 
             }
         }
         __syncthreads();
-        const int K = s_small_n;                             // block-uniform
+        const int K = s_small_n[pp];                         // block-uniform
+        if (tid == 0) s_small_n[pp ^ 1] = 0;                 // nobody looks at the other counter any more; the next pose adds to it after its barrier
         if (K <= CVP_SMALL) {
             if (tid < 64) {
                 // the boxes in order of their left ends (rank by counting; ties by position in the list)
@@ -435,9 +456,8 @@ __global__ __launch_bounds__(CVP_THREADS) __attribute__((amdgpu_waves_per_eu(4, 
             const int k_lo = sq.cv_lo[pass] / CVP_THREADS, k_hi = (sq.cv_hi[pass] + CVP_THREADS - 1) / CVP_THREADS;
             const int nh = (row1 - row0) + 2 * h - 1, ng = (nh + 7) >> 3;
             const int y_base = row0 - h + 1;
+            ++tok;                                           // s_any == tok: somebody painted in this pass (no reset, no barrier for one)
             __syncthreads();                                 // the previous pass (or pose) is done with the rows and has wiped them
-            if (tid == 0) s_any = 0;
-            __syncthreads();
             // paints (wipe = false) or wipes the column intervals of the thread's inliers near this pass's rows
             auto paint = [&](bool wipe) {
                 bool any = false;
@@ -461,9 +481,9 @@ __global__ __launch_bounds__(CVP_THREADS) __attribute__((amdgpu_waves_per_eu(4, 
                 }
                 return any;
             };
-            if (paint(false)) s_any = 1;
+            if (paint(false)) s_any = tok;
             __syncthreads();
-            if (!s_any) continue;                            // no inlier near these rows (block-uniform): nothing painted
+            if (s_any != tok) continue;                      // no inlier near these rows (block-uniform): nothing painted
             for (int g = g_first, c = c_first; g < ng; ) {
                 const unsigned long long *base = Hm + (8 * g) * W + c;
                 unsigned long long r[8];
