@@ -8,8 +8,8 @@ run() { name=$1; shift; timeout -k 10 400 python bench.py "$@" > "$OUT/$name.jso
 run single || exit 1
 run p3p --known-focal --matches 2000 --inlier-frac 0.3 || exit 1
 run large --matches 100000 --inlier-frac 0.01 --hyps 262144 --steps 5 --warmup 1 || exit 1
-run dub_fixed --workload dubrovnik --steps 3 --warmup 1 || exit 1
-run dub_exit --workload dubrovnik --early-exit --steps 3 --warmup 1 || exit 1
-run dub_adv --workload dubrovnik --advanced --steps 3 --warmup 1 || exit 1
+run dub_fixed --workload dubrovnik --steps 10 --warmup 2 || exit 1
+run dub_exit --workload dubrovnik --early-exit --steps 20 --warmup 5 || exit 1
+run dub_adv --workload dubrovnik --advanced --steps 20 --warmup 5 || exit 1
 run gloo2_single --gpus 2 --backend gloo --steps 5 --warmup 1 --no-cpu-baseline || exit 1
 run gloo2_dub --gpus 2 --backend gloo --workload dubrovnik --early-exit --steps 2 --warmup 1 --no-cpu-baseline || exit 1
