@@ -294,6 +294,7 @@ __global__ __launch_bounds__(256) void k_seg_coverage(seg_launch L, seg_cov C, i
 #endif
 constexpr int CVP_THREADS = CVP_T;       // threads per block
 constexpr int CVP_KM = 6144 / CVP_THREADS;   // correspondences per thread
+static_assert(CVP_KM % 4 == 0, "the inlier test takes the correspondences of a thread four at a time");
 constexpr int CVP_BIAS = 16384;          // keypoint coordinates are stored as 16-bit values with this bias
 constexpr int CVP_SMALL = 32;            // poses with at most this many inliers get their area without the bitmap
 constexpr int CVP_PASSES = 16;           // passes a query may need (more: the query's areas come from k_seg_coverage)
