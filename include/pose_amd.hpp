@@ -262,6 +262,11 @@ public:
         return true;
     }
 
+    // query_processor.cpp:36-44: the reference's refinement step is an empty function that returns
+    // true (its Levenberg-Marquardt is a TODO there); Process calls it between ComputeMatrices and
+    // the final Project (basic.cpp:299, advanced.cpp:613), so it exists here with the same effect.
+    bool BundleAdjust(Query &, std::vector<SiftMatch> &, std::vector<SIFT_keypoint> &, std::vector<feature_3D_info> &) { return true; }
+
     // Inliers of query.proj_matrix() among `matches` and the coverage quality (query_processor.cpp:88-177).
     std::vector<SiftMatch> TestHypothesis(Query &query, std::vector<SiftMatch> &matches, std::vector<SIFT_keypoint> &sift_keypoints,
                                           std::vector<feature_3D_info> &sifts, double match_eps, double &fit_quality)

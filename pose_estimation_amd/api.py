@@ -481,6 +481,11 @@ class QueryProcessor:
             return p2[0], p3
         return p2[0][matches], p3[matches]
 
+    def BundleAdjust(self, query, fitted_matches=None):
+        """query_processor.cpp:36-44: an empty function that returns true in the reference (its
+        refinement is a TODO there); called between ComputeMatrices and the final Project."""
+        return True
+
     def TestHypothesis(self, query, match_eps=0.5):
         """Returns (inlier mask over the matches, fit_quality) for query.proj_matrix()."""
         self._upload(query)
@@ -530,6 +535,7 @@ class QueryProcessorBasic(QueryProcessor):
             query.fitted_mask = np.zeros(query.kx.size, bool)
             query.fitpoints_2d, query.fitpoints_3d = np.zeros((0, 2)), np.zeros((0, 3))
         query.ComputeMatrices(self.ctx)
+        self.BundleAdjust(query, query.fitted_mask)
         return True
 
 
@@ -599,4 +605,5 @@ class QueryProcessorAdvanced(QueryProcessorBasic):
             query.fitted_mask = np.zeros(query.kx.size, bool)
             query.fitpoints_2d, query.fitpoints_3d = np.zeros((0, 2)), np.zeros((0, 3))
         query.ComputeMatrices(self.ctx)
+        self.BundleAdjust(query, query.fitted_mask)
         return True

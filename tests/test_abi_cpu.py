@@ -65,3 +65,16 @@ def test_query_partition_is_the_sharding_rule():
             loads = [int(costs[part[:nq] == r].sum()) for r in range(parts)]
             assert max(loads) - min(loads) <= costs.max()
     assert lib.pose_amd_partition_queries(3, None, 2, None) != 0 and lib.pose_amd_partition_queries(3, None, 0, None) != 0
+
+
+def test_facades_have_the_reference_processor_interface():
+    """query_processor.hpp:33-73: Process, Project, TestHypothesis and the (empty) BundleAdjust."""
+    from pose_estimation_amd import api
+    for name in ("Project", "TestHypothesis", "BundleAdjust"):
+        assert callable(getattr(api.QueryProcessor, name))
+    for cls in (api.QueryProcessorBasic, api.QueryProcessorAdvanced):
+        assert callable(cls.Process) and issubclass(cls, api.QueryProcessor)
+    assert api.QueryProcessor.BundleAdjust(None, None) is True      # query_processor.cpp:36-44 returns true and does nothing
+    hpp = open(os.path.join(os.path.dirname(__file__), "..", "include", "pose_amd.hpp")).read()
+    for name in ("bool Project(", "TestHypothesis(", "bool BundleAdjust(", "virtual bool Process("):
+        assert name in hpp
