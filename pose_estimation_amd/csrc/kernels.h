@@ -87,6 +87,13 @@ __device__ __forceinline__ uint32_t draw_at(uint64_t seed, uint32_t query_id, ui
 // intersection when a pick is accepted.  The sets are the same, so are the tuples.
 // One tuple by one wave: `hyp` is the hypothesis id, the tuple goes to samples[4 t], inter / bm are
 // the wave's LDS scratch (MAXCAM words; bm_words words when BITMAP).
+// Two / four consecutive words at a word-aligned address with ONE load instruction: the sampler's
+// loads are gathers (64 lanes, 64 cache lines), and the cache serves a gather line by line, so the
+// number of load instructions per candidate, not the bytes, is what the rounds cost.
+typedef uint32_t words2 __attribute__((ext_vector_type(2), aligned(4)));
+typedef uint32_t words4 __attribute__((ext_vector_type(4), aligned(4)));
+#define POSE_AMD_GLOBAL(T, ptr) ((const __attribute__((address_space(1))) T *)(ptr))    // the arrays of a query are device memory
+
 template <bool BITMAP>
 __device__ __forceinline__ void sample_advanced_wave(const query_dev &q, int m, uint64_t seed, uint32_t query_id, uint32_t hyp, size_t t,
                                                      const double *__restrict__ gain, uint32_t *__restrict__ samples, int *__restrict__ status,
@@ -102,7 +109,8 @@ __device__ __forceinline__ void sample_advanced_wave(const query_dev &q, int m, 
     int i = 0, zero_check = 0;
     while (i < m) {
         const uint32_t idx = (uint32_t)(((uint64_t)draw_at(seed, query_id, hyp, 0, di + lane) * (uint32_t)q.n) >> 32);
-        uint32_t cb = q.cam_off[idx], ce = q.cam_off[idx + 1];
+        const words2 span = *POSE_AMD_GLOBAL(words2, q.cam_off + idx);   // cam_off has n + 1 entries
+        uint32_t cb = span.x, ce = span.y;
         if (ce - cb > (uint32_t)MAXCAM) { bad = 1; ce = cb + MAXCAM; }
         int ev;                                          // lane of the first event
         bool restart = false;
@@ -119,11 +127,15 @@ __device__ __forceinline__ void sample_advanced_wave(const query_dev &q, int m, 
             if (!dup) {
                 if constexpr (BITMAP) {
                     for (uint32_t p = cb; p < ce; p += 4) {
-                        uint32_t a[4];
+                        // up to three words past the set are read and ignored (the next set's; the host leaves 16
+                        // bytes of slack behind the last one)
+                        const words4 w = *POSE_AMD_GLOBAL(words4, q.cam_ids + p);
 #pragma unroll
-                        for (int k = 0; k < 4; ++k) a[k] = q.cam_ids[min(p + (uint32_t)k, ce - 1u)];
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) ncheck += p + (uint32_t)k < ce ? (bm[a[k] >> 5] >> (a[k] & 31u)) & 1u : 0u;
+                        for (int k = 0; k < 4; ++k) {
+                            const bool in = p + (uint32_t)k < ce;
+                            const uint32_t a = in ? w[k] : 0u;
+                            ncheck += in ? (bm[a >> 5] >> (a & 31u)) & 1u : 0u;
+                        }
                     }
                 } else {
                     uint32_t p = cb, r = 0;

@@ -517,7 +517,8 @@ int pose_amd_set_camsets(pose_amd_ctx *ctx, const uint32_t *cam_off, const uint3
     int rc;
     if ((rc = upload(ctx, ctx->cam_off, cam_off, ((size_t)ctx->n + 1) * 4))) return rc;
     const size_t total = cam_off[ctx->n];
-    if ((rc = upload(ctx, ctx->cam_ids, cam_ids, (total ? total : 1) * 4))) return rc;
+    // 16 bytes of slack: the sampler reads a set four words at a time
+    if ((rc = ensure(ctx, ctx->cam_ids, (total ? total : 1) * 4 + 16)) || (rc = upload(ctx, ctx->cam_ids, cam_ids, (total ? total : 1) * 4))) return rc;
     ctx->has_cam = true;
     ctx->cam_max = cam_max;
     return pose_amd_synchronize(ctx);
@@ -1249,7 +1250,7 @@ static int batch_fill(pose_amd_ctx *ctx, pose_amd_batch *b, int nq, const pose_a
             e.cam_off_at = total;
             total += (((size_t)q.n + 1) * 4 + 255) / 256 * 256;
             e.cam_ids_at = total;
-            total += ((size_t)std::max<uint32_t>(q.cam_off[q.n], 1u) * 4 + 255) / 256 * 256;
+            total += ((size_t)std::max<uint32_t>(q.cam_off[q.n], 1u) * 4 + 16 + 255) / 256 * 256;   // 16 bytes of slack: the sampler reads a set four words at a time
         }
     }
     int rc;
