@@ -310,6 +310,39 @@ def test_advanced_samples_bit_exact(ctx):
             assert np.array_equal(got2[h], exp), (shift, h)
 
 
+@pytest.mark.parametrize("last", [1, 2, 3])
+def test_advanced_samples_when_the_id_array_ends_on_a_boundary(ctx, last):
+    """The sampler reads a camera set four ids per load, so the load of the last set can reach past
+    the array: total length a multiple of 64 words (256 bytes), last set of 1-3 ids, and the sets
+    small enough that the last candidate is drawn often.  Tuples equal the oracle's."""
+    n = 96
+    q = synth.make_query(n, 0.5, 21)
+    rng = np.random.default_rng(100 + last)
+    sizes = [int(rng.integers(5, 9)) if i % 3 == 0 else int(rng.integers(2, 5)) for i in range(n - 1)] + [last]
+    while sum(sizes) % 64:                                     # pad an early set, never the last
+        sizes[int(rng.integers(0, n - 1))] += 1
+    off, ids = [0], []
+    for k in sizes:
+        ids.append(np.sort(rng.choice(40, k, replace=False)).astype(np.uint32))
+        off.append(off[-1] + k)
+    q["cam_off"], q["cam_ids"] = np.array(off, np.uint32), np.concatenate(ids)
+    assert q["cam_ids"].size % 64 == 0 and sizes[-1] == last
+    upload(ctx, q)
+    ctx.set_camsets(q["cam_off"], q["cam_ids"])
+    got = ctx.sample(SAMPLE_ADVANCED, 31, 7, 0, 256)
+    for h in range(256):
+        exp, k, kp = O.sample_advanced(31, 7, h, 4, n, q["cam_off"], q["cam_ids"])
+        assert np.array_equal(got[h], exp), h
+    # the same query as the last one of a list (shared launches: the arrays are packed behind one another)
+    q["query_id"] = 7
+    ctx.sample(SAMPLE_ADVANCED, 31, 7, 0, 64, export=False)
+    r = ctx.ransac_run(SELECT_INLIERS, 0.5, False)
+    got = ctx.ransac_batch([q, q], SAMPLE_ADVANCED, seed=31, budget=64, select_mode=SELECT_INLIERS, early_exit=False)
+    for g in got:
+        for k in ("found", "inliers", "steps", "best_hyp", "best_sol", "poses_scored"):
+            assert g[k] == r[k], (k, g[k], r[k])
+
+
 def test_sampler_rejects_bad_input(ctx):
     q = synth.make_query(3, 1.0, 1)
     upload(ctx, q)
