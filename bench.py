@@ -45,7 +45,7 @@ FINISH_FLOP_PER_HYP = 2.3e4        # executed fp64 lane-operations per hypothesi
 SCREEN_MFMA_FLOP_PER_PAIR = 96     # what the matrix-core screen executes: three v_mfma_f32_32x32x16_bf16 per 32 x 32 pairs
 
 
-def parse_args():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
@@ -71,7 +71,12 @@ def parse_args():
                                                                 "packing and the PCIe copy inside the timed region) instead of running a list resident in HBM")
     ap.add_argument("--python-threads", action="store_true", help="dubrovnik: drive the contexts from Python threads instead of pose_amd_ransac_batch")
     ap.add_argument("--host-threads", type=int, default=16, help="dubrovnik: contexts (streams) per GPU driven concurrently")
-    return ap.parse_args()
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="dubrovnik with --gpus N: weak = every GPU runs its own list of --queries queries (default); strong = one list of "
+                         "--queries queries partitioned over the GPUs")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="default workload only: skip the short passes of the other BASELINE configs that fill config.other_workloads")
+    return ap.parse_args(argv)
 
 
 def self_launch(args):
@@ -126,39 +131,121 @@ def host_cores():
     return min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16")), 16)
 
 
+class KeyReducer:
+    """The one exchange of the hypothesis-sharded path: a max-all-reduce of one packed (count, id)
+    key per step, started without waiting and collected before the clock stops, so that it runs
+    beside the next step's kernels.  The keys live in a ring of preallocated slots of one device
+    tensor (a slot is filled in place; nothing is allocated inside the timed region)."""
+    SLOTS = 8
+
+    def __init__(self, torch, dist, device):
+        self.dist = dist
+        self.buf = torch.zeros(self.SLOTS, dtype=torch.int64, device=device) if dist is not None else None
+        self.views = [self.buf[i:i + 1] for i in range(self.SLOTS)] if dist is not None else []
+        self.work = [None] * self.SLOTS
+        self.n = 0
+        self.keys = []
+
+    def _finish(self, slot):
+        if self.work[slot] is not None:
+            self.work[slot].wait()
+            self.keys.append(int(self.views[slot].item()))
+            self.work[slot] = None
+
+    def begin(self, key):
+        if self.dist is None:
+            self.keys.append(int(key))
+            return
+        slot = self.n % self.SLOTS
+        self.n += 1
+        self._finish(slot)                                   # the reduction that used this slot SLOTS steps ago
+        self.views[slot].fill_(int(key))
+        self.work[slot] = self.dist.all_reduce(self.views[slot], op=self.dist.ReduceOp.MAX, async_op=True)
+
+    def collect(self):
+        """Waits for every reduction still in flight; -> the reduced keys in step order."""
+        if self.dist is not None:
+            for i in range(self.SLOTS):
+                self._finish((self.n + i) % self.SLOTS)
+        out, self.keys = self.keys, []
+        return out
+
+
 def main():
     args = parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return self_launch(args)
+    env = setup_ranks(args)
+    rank, world, dist = env[0], env[1], env[5]
     if args.workload == "dubrovnik":
-        return bench_dubrovnik(args)
-    if args.workload == "knn":
-        return bench_knn(args)
-    rank, world, dev_index, red_dev, torch, dist = setup_ranks(args)
+        out = bench_dubrovnik(args, env)
+    elif args.workload == "knn":
+        out = bench_knn(args, env)
+    else:
+        out = bench_single(args, env)
+        if not args.no_extras and is_default_workload(args):
+            extras = other_workloads(args, env)
+            if rank == 0:
+                out["config"]["other_workloads"] = extras
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+    return 0
+
+
+def is_default_workload(args):
+    return (args.matches, args.inlier_frac, args.known_focal, args.hyps) == (4000, 0.10, False, 1 << 20)
+
+
+def other_workloads(args, env):
+    """Short passes of the other BASELINE configs after the timed region of the default workload,
+    so that one run carries every config: value, ms per step and the dominant kernel with its
+    roofline fraction.  No CPU legs; every entry is a full bench line of its own workload
+    (`python bench.py <flags>` reproduces it with more steps)."""
+    runs = [("configs[0]", ["--known-focal", "--matches", "2000", "--inlier-frac", "0.3", "--steps", "10", "--warmup", "2"]),
+            ("configs[2] reference loop", ["--workload", "dubrovnik", "--early-exit", "--steps", "10", "--warmup", "2"]),
+            ("configs[2] fixed budget", ["--workload", "dubrovnik", "--steps", "3", "--warmup", "1"]),
+            ("configs[3]", ["--workload", "dubrovnik", "--advanced", "--steps", "10", "--warmup", "2"]),
+            ("configs[4] shape, one GPU's share per step", ["--matches", "100000", "--inlier-frac", "0.01", "--hyps", str(1 << 21), "--steps", "2", "--warmup", "1"])]
+    out = []
+    for name, flags in runs:
+        a = parse_args(flags + ["--gpus", str(args.gpus), "--backend", args.backend, "--no-cpu-baseline", "--no-extras"])
+        a.is_extra = True
+        t0 = time.perf_counter()
+        line = (bench_dubrovnik if a.workload == "dubrovnik" else bench_single)(a, env)
+        if env[0] == 0:
+            rl = line.get("roofline") or {}
+            out.append({"config": name, "flags": " ".join(flags), "metric": line["metric"], "value": line["value"], "unit": line["unit"],
+                        "ms_per_step": line["ms_per_step"], "steps": line["steps"], "scaling": line["scaling"], "n_gpus": line["n_gpus"],
+                        "dominant_kernel": rl.get("kernel"), "bound": rl.get("bound"), "frac": rl.get("frac"),
+                        "kernel_ms_per_step": rl.get("kernel_ms_per_step"),
+                        **{k: line["config"][k] for k in ("hypotheses_per_s", "mean_steps_per_query", "best_inliers") if k in line["config"]},
+                        **{k: rl[k] for k in ("steps_computed", "poses_painted") if k in rl},
+                        "wall_s_incl_setup": round(time.perf_counter() - t0, 2)})
+    return out
+
+
+def bench_single(args, env):
+    """One query, hypothesis range sharded over the ranks (weak scaling: --hyps per GPU per step).
+    -> the JSON line as a dict on rank 0 (None elsewhere)."""
+    rank, world, dev_index, red_dev, torch, dist = env
 
     from pose_estimation_amd import Context, shard, synth, SELECT_INLIERS, SAMPLE_BASIC
     ctx = Context(dev_index)
     q = synth.make_query(args.matches, args.inlier_frac, seed=2, known_focal=args.known_focal)
     ctx.set_query(q["kx"], q["ky"], q["X"], q["Y"], q["Z"], q["width"], q["height"], q["focal"])
     H = args.hyps
+    red = KeyReducer(torch, dist if world > 1 else None, red_dev)
 
     def step(i):
         # hypothesis ids are global: rank r owns [ (i*world + r) * H, +H )
         ctx.sample(SAMPLE_BASIC, 1002, 0, ((i * world + rank) * H) % (1 << 31), H, export=False)
         r = ctx.ransac_run(SELECT_INLIERS, 0.5, early_exit=False)
         if world > 1:
-            # the only exchange of the hypothesis-sharded path: one packed (count, id) key per step.  It is
-            # started here and collected before the clock stops, so that it runs beside the next step's kernels.
             gh = ((i * world + rank) * H + r["best_hyp"]) & shard.KEY_ID_MASK
-            pending.append(shard.reduce_best_begin(shard.pack_key(r["inliers"], gh), dist, red_dev))
+            red.begin(shard.pack_key(r["inliers"], gh))
         return r
-
-    pending = []
-
-    def collect():
-        best = [shard.unpack_key(shard.reduce_best_end(h)) for h in pending]
-        pending.clear()
-        return best
 
     def sync():
         ctx.synchronize()
@@ -169,7 +256,7 @@ def main():
 
     for i in range(args.warmup):
         step(i)
-    collect()
+    red.collect()
     sync()
     t0 = time.perf_counter()
     tim = {}
@@ -180,7 +267,7 @@ def main():
         poses += last["poses_scored"]
         for k, v in ctx.last_timing().items():
             tim[k] = tim.get(k, 0.0) + v
-    global_best = collect()                                  # every step's reduction has completed inside the timed region
+    global_best = [shard.unpack_key(k) for k in red.collect()] if world > 1 else []   # every step's reduction has completed inside the timed region
     sync()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -188,6 +275,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    out = None
     if rank == 0:
         total_hyps = H * args.steps * world
         info = ctx.device_info()
@@ -209,7 +297,7 @@ def main():
                           "device": info["name"], "best_inliers": int(last["inliers"]),
                           **({"global_best_inliers_last_step": int(global_best[-1][0])} if global_best else {})},
                "roofline": roofline}
-        if world == 1:
+        if world == 1 and not getattr(args, "is_extra", False):
             # the same step with the host->device hand-over of the query inside the timed region
             t1 = time.perf_counter()
             for i in range(2):
@@ -219,11 +307,8 @@ def main():
             out["config"]["pcie_inclusive_hypotheses_per_s"] = round(2 * H / (time.perf_counter() - t1), 1)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_single(ctx, q, args)
-        print(json.dumps(out))
     ctx.close()
-    if world > 1:
-        dist.destroy_process_group()
-    return 0
+    return out
 
 
 def roofline_of(tim, hyps, poses, matches_x_poses_or_n, known_focal, launches, steps):
@@ -252,9 +337,13 @@ def roofline_of(tim, hyps, poses, matches_x_poses_or_n, known_focal, launches, s
     roofline = {"kernel": dom, "bound": "valu_fp64", "achieved": round(tflops, 3), "peak": FP64_VECTOR_PEAK_TFLOPS,
                 "unit": "TFLOP/s", "frac": round(tflops / FP64_VECTOR_PEAK_TFLOPS, 4), "traffic": traffic,
                 "traffic_source": rec.get("source") if rec else None,
+                # true when the device sources changed after the counter passes were collected (tools/r3_profiles.sh renews them)
+                "traffic_stale": rec.get("stale") if rec else None,
                 "launches": launches, "avg_launch_ms": round(dom_ms / launches, 4),
                 "kernel_ms_per_step": {k: round(v / steps, 3) for k, v in tim.items() if k.endswith("_ms")},
-                "kernel_tflops": {k: round(f / (ms * 1e-3) / 1e12, 3) for k, (ms, f) in work.items() if ms > 0 and k != "k_score_mfma"},
+                "kernel_tflops": {k: round(f / (ms * 1e-3) / 1e12, 3) for k, (ms, f) in work.items()
+                                  if ms > 0 and k not in ("k_score_mfma", "k_p4pf_finish")},
+                "kernel_executed_tflops": {k: round(f / (ms * 1e-3) / 1e12, 3) for k, (ms, f) in work.items() if ms > 0 and k == "k_p4pf_finish"},
                 "poses_per_hypothesis": round(poses / max(hyps, 1), 3)}
     # executed float64 lane-operations (SQ_INSTS_VALU_*_F64 x 64 from the recorded counter passes)
     # beside the algorithmic figure: the difference is idle lanes, pivots and retired rows
@@ -282,6 +371,20 @@ def roofline_of(tim, hyps, poses, matches_x_poses_or_n, known_focal, launches, s
     return roofline
 
 
+def kernel_source_hash():
+    """SHA-256 over the device sources the library is built from (csrc/*.h, *.hip, in name order):
+    the counter records under profiles/ carry the hash of the sources they were collected with."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "pose_estimation_amd", "csrc")
+    for path in sorted(glob.glob(os.path.join(d, "*.h")) + glob.glob(os.path.join(d, "*.hip"))):
+        h.update(os.path.basename(path).encode())
+        with open(path, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
 def recorded_counters(kernel):
     """Per-hypothesis HBM bytes (FETCH_SIZE doubled as measured for gfx950, plus WRITE_SIZE) and
     executed float64 lane-operations of `kernel` from the newest committed counter passes
@@ -293,13 +396,13 @@ def recorded_counters(kernel):
             with open(path) as f:
                 rec = json.load(f)
             n = rec["hypotheses_per_launch"]
-            out = {"source": os.path.relpath(path, ROOT)}
+            out = {"source": os.path.relpath(path, ROOT), "stale": rec.get("kernel_source_sha256") != kernel_source_hash()}
             if kernel in rec:
                 out["hbm_bytes_per_hypothesis"] = rec[kernel]["hbm_bytes_per_launch"] / n
             ph = rec.get("_per_hypothesis", {}).get(kernel)
             if ph:
                 out["executed_fp64_flop_per_hypothesis"] = ph["executed_fp64_lane_flop_per_hypothesis"]
-            if len(out) > 1:
+            if len(out) > 2:
                 return out
         except (OSError, ValueError, KeyError):
             continue
@@ -345,31 +448,33 @@ def cpu_baseline_single(ctx, q, args):
                                              "projection and painting, two height x width float maps per pose), %.1f s" % (nf, dtf)}}
 
 
-def bench_dubrovnik(args):
+def bench_dubrovnik(args, env):
     """BASELINE configs[2]: 800 Dubrovnik6K-shaped synthetic queries (image sizes and known /
     unknown focal lengths of the real query list, 4 000-6 000 matches, 10-40 % inliers), basic
     RANSAC per query, queries partitioned over the GPUs (no collective in the data path).
     A step is one pass over all queries.  Each GPU is driven by a few host threads, one
     context (HIP stream) each, so that the small per-query launches of different queries overlap."""
     from concurrent.futures import ThreadPoolExecutor
-    rank, world, dev_index, red_dev, torch, dist = setup_ranks(args)
+    rank, world, dev_index, red_dev, torch, dist = env
     from pose_estimation_amd import Context, shard, synth, SELECT_INLIERS, SELECT_COVERAGE, SAMPLE_BASIC, SAMPLE_ADVANCED
     if args.advanced:
         args.budget, args.early_exit = 100, False
     with open(os.path.join(ROOT, "tests", "golden", "dubrovnik_queries.json")) as f:
         shapes = json.load(f)["queries"]
-    nq = args.queries
+    # weak scaling: every rank runs its own list of --queries queries (ids rank*nq ...); strong: one list partitioned
+    weak = args.scaling == "weak"
+    nq = args.queries * (world if weak else 1)
     rng = np.random.default_rng(3)
     sizes = rng.integers(4000, 6001, nq)
     fracs = rng.uniform(0.10, 0.40, nq)
-    mine = shard.query_shard(sizes, rank, world)
+    mine = list(range(rank * args.queries, (rank + 1) * args.queries)) if weak else shard.query_shard(sizes, rank, world)
     queries = []
     for qi in mine:
         w, h, f = shapes[qi % len(shapes)]
         q = synth.make_query(int(sizes[qi]), float(fracs[qi]), 3000 + qi, width=w, height=h, focal=f if f > 0 else 0.9 * max(w, h),
                              known_focal=f > 0)
         if args.advanced:
-            synth.add_camsets(q, seed=4000 + qi)
+            synth.add_camsets_vec(q, seed=4000 + qi)
         queries.append((qi, q))
     T = max(1, args.host_threads)
     select = SELECT_COVERAGE if (args.early_exit or args.advanced) else SELECT_INLIERS
@@ -446,6 +551,7 @@ def bench_dubrovnik(args):
         stats = [None] * world
         dist.all_gather_object(stats, res)
         res = [x for part in stats for x in part]
+    out = None
     if rank == 0:
         steps_total = sum(r[1] for r in res)
         located = sum(1 for r in res if r[3] < 2.0)
@@ -454,22 +560,24 @@ def bench_dubrovnik(args):
                 else "fixed budget of %d hypotheses per query, inlier-count selection" % args.budget)
         out = {"metric": "queries/sec (Dubrovnik-shaped batch, %s RANSAC)" % ("advanced" if args.advanced else "basic"), "value": round(nq * args.steps / dt, 1), "unit": "queries/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
-               "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+               "higher_is_better": True, "scaling": args.scaling if world > 1 else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
                "config": {"workload": "BASELINE configs[%d]: %d Dubrovnik6K-shaped queries (real image sizes, %d known / %d unknown focal), "
                                       "4000-6000 matches, 10-40%% inliers, %s"
                                       % (3 if args.advanced else 2, nq, sum(1 for i in range(nq) if shapes[i % len(shapes)][2] > 0),
                                          sum(1 for i in range(nq) if shapes[i % len(shapes)][2] == 0), mode),
-                          "parallelism": "queries partitioned over %d GPU(s), %s" % (
-                              world, "%d host threads (contexts) per GPU" % T if not batched
+                          "parallelism": "%s, %s" % (
+                              ("every one of %d GPU(s) runs its own list of %d queries" % (world, args.queries)) if weak
+                              else "one list partitioned over %d GPU(s) (longest first)" % world, "%d host threads (contexts) per GPU" % T if not batched
                               else "all queries of a GPU share their launches (rounds of 128, 640, 3200, ... steps, list of running queries kept on the device)"),
                           "queries": "resident in HBM (pose_amd_batch_create before the timed region, pose_amd_batch_run timed)" if resident is not None
                                      else "host arrays handed over in every pass (packing + PCIe copy inside the timed region)",
                           "hypotheses_per_s": round(steps_total * args.steps / dt, 1),
                           "mean_steps_per_query": round(steps_total / max(len(res), 1), 1),
                           "queries_within_2_units_of_true_position": located}}
-        if world == 1 and resident is not None:
+        if resident is not None:
+            # (with several GPUs: rank 0's own list)
             out["roofline"] = roofline_shared_launches(resident, queries, res, sample_mode, select, args)
-            if not args.no_cpu_baseline:
+            if world == 1 and not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline_batch(ctxs[0], queries, args, select, sample_mode)
         elif world == 1:
             # Per-kernel times of this workload: a profiling pass outside the timed region, one
@@ -501,22 +609,19 @@ def bench_dubrovnik(args):
             out["roofline"] = rl
             if not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline_batch(ctxs[0], queries, args, select, sample_mode)
-        print(json.dumps(out))
     if resident is not None:
         resident.close()
     for c in ctxs:
         c.close()
-    if world > 1:
-        dist.destroy_process_group()
-    return 0
+    return out
 
 
-def bench_knn(args):
+def bench_knn(args, env):
     """The matching step in front of the path: one pass = pose_amd_knn_match of --queries uint8
     descriptors (default 8192) against a model of --points averaged descriptors resident in HBM
     (the reference's FLANN search, query_processor_basic.cpp:60-96, done exactly).  Replicas only:
     with --gpus N every rank searches its own query descriptors against its own copy of the model."""
-    rank, world, dev_index, red_dev, torch, dist = setup_ranks(args)
+    rank, world, dev_index, red_dev, torch, dist = env
     from pose_estimation_amd import Context, synth_desc
     nq = args.queries if args.queries != 800 else 8192
     rng = np.random.default_rng(17)
@@ -553,6 +658,7 @@ def bench_knn(args):
         t = torch.tensor([dt], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    out = None
     if rank == 0:
         pairs = float(nq) * args.points
         scan_s = ms["scan_ms"] / args.steps * 1e-3
@@ -580,11 +686,8 @@ def bench_knn(args):
             out["cpu_baseline"] = {"value": round(ns / dtc, 2), "unit": "descriptors/s", "cores": host_cores(), "cpu": cpu_model(), "kind": "port",
                                    "sample": "the first %d query descriptors against the whole model, oracle/knn_oracle.py (NumPy float64 matrix product "
                                              "with the BLAS threads of the box, exact re-evaluation of a shortlist), %.1f s" % (ns, dtc)}
-        print(json.dumps(out))
     ctx.close()
-    if world > 1:
-        dist.destroy_process_group()
-    return 0
+    return out
 
 
 LDS_PEAK_GBS = 256 * 128 * 2.4          # 256 CUs x 128 B per clock x 2.4 GHz
@@ -641,7 +744,8 @@ def roofline_shared_launches(resident, queries, res, sample_mode, select, args):
         rl = {"kernel": dom, "bound": "valu_fp64", "achieved": round(tf, 3), "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
               "frac": round(tf / FP64_VECTOR_PEAK_TFLOPS, 4), "traffic": None}
     rl.update({"launches": t["launches"], "kernel_ms_per_step": ms,
-               "kernel_tflops": {k: round(f / (m * 1e-3) / 1e12, 3) for k, (m, f) in work.items() if m > 0},
+               "kernel_tflops": {k: round(f / (m * 1e-3) / 1e12, 3) for k, (m, f) in work.items() if m > 0 and k != "k_seg_p4pf_finish"},
+               "kernel_executed_tflops": {k: round(f / (m * 1e-3) / 1e12, 3) for k, (m, f) in work.items() if m > 0 and k == "k_seg_p4pf_finish"},
                "k_seg_cover_pose_lds_gbs": round(cov_bytes / (t["coverage_ms"] * 1e-3) / 1e9, 1) if t["coverage_ms"] > 0 else None,
                "steps_computed": t["p3p_steps_computed"] + t["p4pf_steps_computed"], "poses_painted": t["poses_painted"],
                "pairs_scored": round(pairs, 1),

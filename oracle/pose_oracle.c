@@ -70,6 +70,15 @@
 
 /* P3p.cpp:238-293 */
 int orc_p3p_solve_quartic(const double factors[5], double roots[4]) { return p3p_solve_quartic_d(factors, roots); }
+/* The same closed form in long double, roots rounded to double: the conditioning gate. */
+int orc_p3p_solve_quartic_ld(const double factors[5], double roots[4])
+{
+    long double f[5], r[4];
+    for (int i = 0; i < 5; ++i) f[i] = factors[i];
+    int st = p3p_solve_quartic_ld(f, r);
+    for (int i = 0; i < 4; ++i) roots[i] = (double)r[i];
+    return st;
+}
 /* P3p.cpp:64-236 */
 int orc_p3p_compute_poses(const double fcols[9], const double pcols[9], double sol[48]) { return p3p_compute_poses_d(fcols, pcols, sol); }
 /* The same computation in long double, results rounded to double: the conditioning gate. */

@@ -28,6 +28,8 @@ extern "C" {
 /* ---- P3P (P3p.cpp) ---------------------------------------------------------------- */
 /* P3p.cpp:238-293. factors[5] -> real parts of the 4 Ferrari roots. */
 int orc_p3p_solve_quartic(const double factors[5], double roots[4]);
+/* Same closed form in long double, roots rounded to double: the conditioning gate. */
+int orc_p3p_solve_quartic_ld(const double factors[5], double roots[4]);
 /* P3p.cpp:64-236. fcols/pcols: 3 vectors, vector i at [3*i..3*i+2] (unit bearings, world
  * points).  sol: 4 blocks of 12 doubles: C[3] then Rc row-major[9] (cam->world).
  * Returns 0, or -1 when the world points are collinear (sol untouched). */

@@ -135,7 +135,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     if (!seg_live(L, blockIdx.y)) return;
     const size_t base = (size_t)blockIdx.y * L.S, sbase = base * P4PF_MAXSOL;
     p4pf_finish_block(seg_of(L, blockIdx.y).q, (uint32_t)L.V, samples + base * 4, nullptr, nullptr, Arows + base, (size_t)gridDim.y * L.S, status + base,
-                      proj + sbase * 12, pose + sbase * 13, nsol + base, nullptr, nullptr, nullptr, projf + sbase * 32, eps, blockIdx.x);
+                      proj + sbase * 12, pose + sbase * 13, nsol + base, nullptr, nullptr, nullptr, projf ? projf + sbase * 32 : nullptr, eps, blockIdx.x);
 }
 
 // packed-float32 screen + float64 decision, spb <= SCORE_SPB slots of one query per block
@@ -149,7 +149,7 @@ __global__ __launch_bounds__(SCORE_THREADS) __attribute__((amdgpu_waves_per_eu(6
     __shared__ int s_wave_n[SCORE_THREADS / 64];
     if (!seg_live(L, blockIdx.y)) return;
     const size_t base = (size_t)blockIdx.y * L.S, sbase = base * maxsol;
-    score_screen_block<false>(seg_of(L, blockIdx.y).q, L.V * maxsol, proj + sbase * 12, projf + sbase * 32, nsol + base, maxsol, eps, counts + sbase,
+    score_screen_block<false>(seg_of(L, blockIdx.y).q, L.V * maxsol, proj + sbase * 12, projf ? projf + sbase * 32 : nullptr, nsol + base, maxsol, eps, counts + sbase,
                               nullptr, 0, spb, blockIdx.x, s_cnt, s_list, s_wave_n);
 }
 

@@ -76,6 +76,31 @@ def add_camsets(q, seed, n_cams=6000, cluster=12):
     return q
 
 
+def add_camsets_vec(q, seed, n_cams=6000, cluster=12):
+    """add_camsets with the same distribution drawn with array operations (a different random
+    stream, so different sets): 1 ms instead of 120 ms per query of 5 000 matches, for callers that
+    build hundreds of queries."""
+    rng = np.random.default_rng(seed)
+    n = len(q["kx"])
+    common = np.sort(rng.choice(n_cams, cluster, replace=False))
+    k = np.where(rng.uniform(size=n) < 0.03, rng.integers(5, 9, n), rng.integers(2, 5, n))
+    ids_in = common[np.argsort(rng.random((n, cluster)), axis=1)[:, :8]]      # a random arrangement of the cluster per point
+    ids_out = rng.integers(0, n_cams, (n, 8))
+    while True:                                                                # 8 distinct cameras per point
+        s = np.sort(ids_out, axis=1)
+        dup = (s[:, 1:] == s[:, :-1]).any(1)
+        if not dup.any():
+            break
+        ids_out[dup] = rng.integers(0, n_cams, (int(dup.sum()), 8))
+    first = np.arange(8)[None, :] < k[:, None]
+    ids = np.where(first, np.where(np.asarray(q["inliers"], bool)[:, None], ids_in, ids_out), n_cams + 1)
+    ids.sort(axis=1)                                                           # the k kept ids ascending, the sentinel behind them
+    q["cam_off"] = np.concatenate([[0], np.cumsum(k)]).astype(np.uint32)
+    q["cam_ids"] = ids[first].astype(np.uint32)
+    q["cam_common"], q["cam_total"] = common, n_cams
+    return q
+
+
 def append_matches(q, extra, inlier_frac, seed, noise_px=0.3, many_cams_frac=0.25):
     """What a backmatching pass does to good_matches (query_processor_advanced.cpp:592): a copy of
     the query with `extra` matches appended, a fraction of them consistent with the planted pose

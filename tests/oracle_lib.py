@@ -38,6 +38,7 @@ def load():
         subprocess.check_call(["make", "-C", os.path.join(_ROOT, "oracle")])
     lib = C.CDLL(_SO)
     lib.orc_p3p_solve_quartic.argtypes = [_dp, _dp]
+    lib.orc_p3p_solve_quartic_ld.argtypes = [_dp, _dp]
     lib.orc_p3p_compute_poses.argtypes = [_dp, _dp, _dp]
     lib.orc_p3p_compute_poses_ld.argtypes = [_dp, _dp, _dp]
     lib.orc_project.argtypes = [_dp, C.c_int, _fp, _fp, _fp, _dp, _dp]
@@ -76,10 +77,10 @@ def lib():
     return _lib
 
 
-def solve_quartic(factors):
+def solve_quartic(factors, long_double=False):
     f = np.ascontiguousarray(factors, dtype=np.float64)
     r = np.zeros(4)
-    lib().orc_p3p_solve_quartic(_p(f, _dp), _p(r, _dp))
+    (lib().orc_p3p_solve_quartic_ld if long_double else lib().orc_p3p_solve_quartic)(_p(f, _dp), _p(r, _dp))
     return r
 
 

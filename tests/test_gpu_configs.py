@@ -93,6 +93,7 @@ def test_dubrovnik_batch_fixed_budget_equals_oracle(ctx):
     queries = dubrovnik_queries()[:6]
     budget, seed = 1500, 3000
     got = ctx.ransac_batch(queries, SAMPLE_BASIC, seed=seed, budget=budget, select_mode=SELECT_INLIERS, early_exit=False)
+    compared = 0
     for q, g in zip(queries, got):
         ctx.set_query(*oracle_args(q))
         s = ctx.sample(SAMPLE_BASIC, seed, q["query_id"], 0, budget)
@@ -100,7 +101,40 @@ def test_dubrovnik_batch_fixed_budget_equals_oracle(ctx):
         o = O.ransac(*oracle_args(q), s, select_coverage=False, early_exit=False, max_steps=budget)
         assert (g["found"], g["steps"], g["best_hyp"], g["inliers"]) == (o["found"], budget, o["best_step"], o["hyposet"])
         if g["best_sol"] == o["best_sol"]:
-            assert_pose_close(q, s[g["best_hyp"]], g, o)
+            compared += assert_pose_close(q, s[g["best_hyp"]], g, o)
+    assert compared >= len(queries) - 2, compared
+
+
+def test_dubrovnik_batch_advanced_equals_oracle(ctx):
+    """BASELINE configs[3] at its own size: ten entries of the Dubrovnik fixture with camera sets
+    (4 000-6 000 matches, 2-4 cameras per point, inliers sharing a cluster) through the shared
+    launches with the co-occurrence sampler, 100 steps, coverage-quality selection, no early exit
+    (query_processor_advanced.cpp:296-581) -- tens of poses per query go through the candidate path
+    and the one-block-per-pose coverage kernel.  Tuples (spot-checked), kept hypothesis, inliers and
+    both areas equal the oracle's loop on the exported tuples; poses at the gated bar."""
+    queries = dubrovnik_queries()
+    for i, q in enumerate(queries):
+        synth.add_camsets_vec(q, seed=4000 + i)
+    seed = 3000
+    got = ctx.ransac_batch(queries, SAMPLE_ADVANCED, seed=seed, budget=100, select_mode=SELECT_COVERAGE, early_exit=False)
+    compared = 0
+    for q, g in zip(queries, got):
+        ctx.set_query(*oracle_args(q))
+        ctx.set_camsets(q["cam_off"], q["cam_ids"])
+        s = ctx.sample(SAMPLE_ADVANCED, seed, q["query_id"], 0, 100)
+        m = 4 if q["focal"] == 0 else 3
+        for h in (0, 37, 99):
+            assert np.array_equal(s[h, :m], O.sample_advanced(seed, q["query_id"], h, m, len(q["kx"]), q["cam_off"], q["cam_ids"])[0][:m])
+        s[:, 3] = np.where(s[:, 3] == 0xFFFFFFFF, 0, s[:, 3])
+        o = O.ransac(*oracle_args(q), s, select_coverage=True, early_exit=False, max_steps=100)
+        key = (q["width"], q["height"], q["focal"], len(q["kx"]))
+        assert (g["found"], g["steps"], g["area_all"]) == (o["found"], 100, o["area_all"]), key
+        assert (g["best_hyp"], g["inliers"], g["area_fit"]) == (o["best_step"], o["hyposet"], o["area_fit"]), key
+        assert abs(g["poses_scored"] - o["poses_scored"]) <= 2, key    # root sets of the two eigen-solvers differ on < 0.1 % of the samples
+        assert g["inliers"] > 0.08 * len(q["kx"]), key              # the sampler finds the planted pose within 100 steps
+        if g["best_sol"] == o["best_sol"]:
+            compared += assert_pose_close(q, s[g["best_hyp"]], g, o)
+    assert compared >= len(queries) - 2, compared
 
 
 # ---- Project ---------------------------------------------------------------------------------------
@@ -189,14 +223,26 @@ def test_advanced_backmatching_leg_equals_oracle(ctx, n, n_in, seed, extra_frac,
     assert qp.best_leg == o["best_leg"]
     assert (r["best_hyp"], r["inliers"], r["area_fit"], r["area_all"]) == (o["best_step"], o["hyposet"], o["area_fit"], o["area_all"])
     dd, ss = (d2, s2) if o["best_leg"] else (d, s1)
+    BACKMATCH_COMPARED.append(False)
     if r["best_sol"] == o["best_sol"]:
         got = dict(focal=q.focal_length(), C=q.camera_position(), Rc=q.camera_rotation())
-        assert_pose_close(dd, ss[r["best_hyp"]], got, o)
+        BACKMATCH_COMPARED[-1] = assert_pose_close(dd, ss[r["best_hyp"]], got, o)
         # the caller's Query holds the kept pose, its projection matrix and the fitted matches
         assert np.array_equal(q.camera_position(), r["C"]) and np.array_equal(q.camera_rotation(), r["Rc"])
         diff = np.nonzero(q.fitted_mask[:len(o["mask"])] != o["mask"].astype(bool))[0]
         assert len(diff) == 0 and not q.fitted_mask[len(o["mask"]):].any()
     assert q.fitpoints_2d.shape == (int(q.fitted_mask.sum()), 2)
+
+
+BACKMATCH_COMPARED = []
+
+
+def test_advanced_backmatching_cases_compared_their_poses():
+    """The five cases above compare the kept pose only for equal solution indices and gated
+    samples; at least three of them must have done so."""
+    if not BACKMATCH_COMPARED:
+        pytest.skip("the backmatching cases did not run in this session")
+    assert sum(BACKMATCH_COMPARED) >= 3, BACKMATCH_COMPARED
 
 
 def test_advanced_without_backmatching_when_first_leg_succeeds(ctx):
@@ -237,7 +283,7 @@ def test_eigen_step_root_sets_on_benchmark_stream(ctx, record_property):
     for k, v in rates.items():
         record_property(k, v)
     assert stable.mean() > 0.97
-    assert rates["on_stable_tuples"] < 0.01, rates
+    assert rates["on_stable_tuples"] < 0.002, rates          # measured 0.0005; a regression of the root finder shows as several times that
 
 
 # ---- the multi-query entry point against the per-query sequence ----------------------------------------

@@ -58,13 +58,20 @@ def test_quartic_batch(ctx):
     rng = np.random.default_rng(0)
     fac = np.concatenate([np.array([np.poly(rng.uniform(-2, 2, 4)) for _ in range(500)]), rng.normal(size=(500, 5))])
     got = ctx.quartic_batch(fac)
-    exp = np.array([O.solve_quartic(f) for f in fac])
-    # the same four roots; the order follows the cube-root branch, which both sides take alike
-    bad = 0
-    for g, e in zip(got, exp):
-        if not np.allclose(g, e, rtol=1e-7, atol=1e-9):
-            bad += not np.allclose(np.sort(g), np.sort(e), rtol=1e-6, atol=1e-8)
-    assert bad <= 2
+    # Bar: 1e-8 relative, or 20 x the closed form's own rounding uncertainty on the polynomial (double
+    # oracle against the same formulas in long double); same order of the four roots (the order follows
+    # the cube-root branch, which both sides take alike)
+    agree = tight = 0
+    worst = 0.0
+    for g, f in zip(got, fac):
+        ld = O.solve_quartic(f, long_double=True)
+        e_ref = relerr(O.solve_quartic(f), ld, 1e-3)
+        tight += e_ref < 1e-9
+        ratio = relerr(g, ld, 1e-3) / max(RTOL, 20 * e_ref)
+        worst = max(worst, ratio)
+        agree += ratio < 1.0
+    assert tight >= 990, tight
+    assert agree >= len(fac) - 1, f"{len(fac) - agree} of {len(fac)} beyond max(1e-8, 20 e_ref); worst ratio {worst:.2f}"
 
 
 def test_p3p_batch_random(ctx):
@@ -159,17 +166,32 @@ def test_p4pf_batch_ragged_counts(ctx, count):
 
 
 def test_p4pf_lapack_fixture(ctx):
+    """Committed problems whose roots (f, zb, zc, zd) come from LAPACK's eigen-solver (tools/gen_golden.py):
+    the focal lengths against that fixture, and f, R, t against the long-double oracle, both at the
+    gated bar.  Solution SETS are compared (sorted by focal length): the device orders solutions by
+    ascending depth of the fourth point, LAPACK / Eigen by eigenvalue order."""
     g = json.load(open(os.path.join(GOLD, "p4pf_lapack.json")))
     m = np.array([x["m2d"] for x in g]); M = np.array([x["M3D"] for x in g])
     nsol, f, R, t = ctx.p4pf_batch(m, M)
-    ok = 0
+    ok = gated = 0
     for i, x in enumerate(g):
         ref = np.array(x["roots"]).reshape(-1, 4)
+        gate = p4pf_gate(m[i], M[i])
+        if gate is None:
+            continue
+        gated += 1
+        n0, f0, R0, t0, e_ref = gate
+        tol = max(RTOL, 20 * e_ref)
         v2 = np.mean(np.linalg.norm(m[i], axis=1))
-        # solution SETS are compared (sorted by focal length): the device orders solutions by
-        # ascending depth of the fourth point, LAPACK / Eigen by eigenvalue order
-        ok += nsol[i] == len(ref) and (len(ref) == 0 or relerr(np.sort(f[i, :len(ref)]), np.sort(ref[:, 0] * v2)) < 1e-7)
-    assert ok >= len(g) - 1
+        if nsol[i] != len(ref) or nsol[i] != n0:
+            continue
+        k = int(nsol[i])
+        od, oo = np.argsort(f[i, :k]), np.argsort(f0)
+        good = k == 0 or (relerr(np.sort(f[i, :k]), np.sort(ref[:, 0] * v2)) < tol and relerr(f[i, :k][od], f0[oo]) < tol and
+                          relerr(R[i, :k][od], R0[oo], 1e-3) < tol and relerr(t[i, :k][od], t0[oo], 1e-3) < tol)
+        ok += good
+    assert gated >= len(g) - 2, gated
+    assert ok >= gated - 1, (ok, gated)
 
 
 # ---- projection + scoring -----------------------------------------------------------------
@@ -392,7 +414,17 @@ def assert_same_outcome(ctx, q, r, o, select):
             assert abs(r["focal"] - o["focal"]) <= tol * abs(o["focal"])
         P = O.compute_matrices(o["focal"], o["C"], o["Rc"])
         assert_masks_equal(q, P, mask, o["mask"])
-    return r["best_sol"] == o["best_sol"]
+        return tol is not None
+    return False
+
+
+def check_outcome(ctx, q, r, o, select):
+    compared = assert_same_outcome(ctx, q, r, o, select)
+    if compared is not None:                 # None: the loop kept no pose
+        POSES_COMPARED.append(bool(compared))
+
+
+POSES_COMPARED = []          # one entry per assert_same_outcome call of the loop tests: was the kept pose compared at the gated bar?
 
 
 @pytest.mark.parametrize("select", [SELECT_COVERAGE, SELECT_INLIERS])
@@ -403,7 +435,7 @@ def test_ransac_p3p_config1(ctx, select, early_exit):
     samples = np.array([np.append(O.sample_basic(1001, 0, h, 3, 2000)[0][:3], 0xFFFFFFFF) for h in range(400)], np.uint32)
     samples[:, 3] = 0
     r, o = run_both(ctx, q, samples, select, early_exit, 400)
-    assert_same_outcome(ctx, q, r, o, select)
+    check_outcome(ctx, q, r, o, select)
     assert np.linalg.norm(r["C"] - q["C_true"]) < 0.5
     if early_exit:
         assert r["steps"] < 400 and r["inliers"] >= 12
@@ -428,7 +460,7 @@ def test_ransac_p4pf_small(ctx, select):
             tot += 1
             agree += r["nsol"][h] == g[0]
         assert agree >= tot - 1
-        assert_same_outcome(ctx, q, r, o, select)
+        check_outcome(ctx, q, r, o, select)
         assert abs(r["focal"] - q["f_true"]) / q["f_true"] < 0.02
 
 
@@ -472,7 +504,13 @@ def test_query_processor_advanced_process(ctx):
     assert qp.Process(q) is True and qp.steps == 100               # exactly 100 steps, no early exit
     o = O.ransac(d["kx"], d["ky"], d["X"], d["Y"], d["Z"], d["width"], d["height"], 0.0, qp.samples,
                  select_coverage=True, early_exit=False, max_steps=100)
-    assert np.linalg.norm(q.camera_position() - o["C"]) < 1e-6 * max(1.0, np.linalg.norm(o["C"]))
+    r = qp.result
+    assert (r["best_hyp"], r["inliers"], r["area_fit"], r["area_all"]) == (o["best_step"], o["hyposet"], o["area_fit"], o["area_all"])
+    assert r["best_sol"] == o["best_sol"]
+    tol = pose_tolerance(d, qp.samples[r["best_hyp"]])
+    assert tol is not None and tol < 1e-6, tol                      # the kept sample of this seed is gated
+    assert relerr(q.camera_position(), o["C"], 1e-3) < tol and relerr(q.camera_rotation(), o["Rc"], 1e-3) < tol
+    assert abs(q.focal_length() - o["focal"]) <= tol * abs(o["focal"])
     assert np.linalg.norm(q.camera_position() - d["C_true"]) < 0.5
 
 
@@ -793,4 +831,13 @@ def test_ransac_early_exit_across_chunks(ctx, select, known_focal, n, frac, step
     s[:, 3] = np.where(s[:, 3] == 0xFFFFFFFF, 0, s[:, 3])
     r, o = run_both(ctx, q, s, select, True, steps)
     assert o["steps"] > 1024                      # the first chunk did not end it
-    assert_same_outcome(ctx, q, r, o, select)
+    check_outcome(ctx, q, r, o, select)
+
+
+def test_zz_loop_tests_compared_their_poses():
+    """The loop tests above compare the kept pose only when device and oracle kept the same
+    solution of the same hypothesis and the sample is gated; they must not stay green with nothing
+    compared.  (Runs after them: pytest keeps file order.)"""
+    if not POSES_COMPARED:
+        pytest.skip("the loop tests did not run in this session")
+    assert sum(POSES_COMPARED) >= 0.7 * len(POSES_COMPARED), (sum(POSES_COMPARED), len(POSES_COMPARED))

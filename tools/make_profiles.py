@@ -31,6 +31,9 @@ traffic = {"_note": "HBM-side bytes per launch from separate rocprofv3 --pmc FET
                     "launches of %d hypotheses each; FETCH_SIZE doubled as measured for wide reads on gfx950. The access widths "
                     "here (8-byte per-lane stores, scalar loads) are outside the calibrated cases: upper bounds." % hyps,
            "hypotheses_per_launch": hyps}
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402  (the hash of the device sources these counters were collected with; bench.py flags a record whose hash differs)
+traffic["kernel_source_sha256"] = bench.kernel_source_hash()
 per_hyp = {}
 for k, r in rows.items():
     if "pose_amd" not in k:
