@@ -21,11 +21,11 @@ $(SHIM): tests/host_shim/eig_shim.hip $(HDRS)
 
 # Test drivers of the C++ host facade (plain g++, link the library through its C ABI; the GPU
 # one also links the CPU oracle, as its checker).
-$(FACADE_TEST): tests/cpp/facade_test.cpp include/pose_amd.hpp include/pose_amd_io.hpp include/pose_amd.h $(LIB) oracle
+$(FACADE_TEST): tests/cpp/facade_test.cpp include/pose_amd.hpp include/pose_amd_types.hpp include/pose_amd_io.hpp include/pose_amd.h $(LIB) oracle
 	g++ -std=c++17 -O1 -Wall -Iinclude $< -o $@ -Lpose_estimation_amd -lpose_amd -Loracle/build -loracle \
 	    -Wl,-rpath,'$$ORIGIN/../../pose_estimation_amd' -Wl,-rpath,'$$ORIGIN/../../oracle/build'
 
-$(IO_TEST): tests/cpp/io_test.cpp include/pose_amd.hpp include/pose_amd_io.hpp include/pose_amd.h $(LIB)
+$(IO_TEST): tests/cpp/io_test.cpp include/pose_amd.hpp include/pose_amd_types.hpp include/pose_amd_io.hpp include/pose_amd.h $(LIB)
 	g++ -std=c++17 -O1 -Wall -Iinclude $< -o $@ -Lpose_estimation_amd -lpose_amd -Wl,-rpath,'$$ORIGIN/../../pose_estimation_amd'
 
 oracle:

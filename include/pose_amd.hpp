@@ -6,9 +6,9 @@
 //   P4pf::P4Pf_m / P4Pf                                  (P4pf.hpp:39-41)
 //   QueryProcessor::Project, TestHypothesis, QueryProcessorBasic/Advanced::Process
 //                                                        (query_processor.hpp:33-73)
+//   QueryLoader / Query (list file, .key files)          (query_loader.hpp:30-91)
 // The reference passes Eigen matrices by value; Eigen is not a dependency here, so the small
-// fixed-size type Mat<R,C> below is used instead.  It is column-major and contiguous like
-// Eigen::Matrix<double,R,C>, so an Eigen build can construct it from `m.data()`.
+// fixed-size type Mat<R,C> of pose_amd_types.hpp is used instead.
 //
 // Error behaviour follows the reference: the solvers return 0 / -1 and never throw; Process
 // always returns true.  A missing GPU or a failed HIP call is not a reference condition: it
@@ -16,29 +16,19 @@
 #pragma once
 #include <algorithm>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
+#include <fstream>
+#include <memory>
 #include <set>
 #include <stdexcept>
 #include <string>
 #include <vector>
 
 #include "pose_amd.h"
+#include "pose_amd_types.hpp"
 
 namespace pose_estimation_amd {
-
-template <int R, int C>
-struct Mat {
-    double v[R * C];
-    Mat() { std::memset(v, 0, sizeof v); }
-    explicit Mat(const double *colmajor) { std::memcpy(v, colmajor, sizeof v); }
-    double &operator()(int r, int c) { return v[c * R + r]; }
-    double operator()(int r, int c) const { return v[c * R + r]; }
-    double *data() { return v; }
-    const double *data() const { return v; }
-};
-using Matrix3d = Mat<3, 3>;
-using Vector3d = Mat<3, 1>;
-using Vector2d = Mat<2, 1>;
 
 // One context per device, created on first use (the reference creates one solver object per
 // Process call, basic.cpp:100-101; contexts are heavier, so they are shared per thread).
@@ -129,21 +119,6 @@ private:
     Device *dev_;
 };
 
-// ---- correspondence records (query_processor.hpp:20-31, SIFT_keypoint.hpp:35-55, parse_bundler.hpp:52-97)
-struct SiftMatch {
-    unsigned int lindex = 0;    // query keypoint
-    unsigned int mindex = 0;    // 3D point
-    float distance = 0.0f;
-    std::set<unsigned int> camset;
-};
-struct SIFT_keypoint { float x = 0, y = 0, scale = 0, orientation = 0; };
-struct point3D { float x = 0, y = 0, z = 0; };
-// parse_bundler.hpp:125-175: a 3-D point and the SIFT descriptors of its views (128 bytes per view)
-struct feature_3D_info {
-    point3D point;
-    std::vector<unsigned char> descriptors;
-};
-
 // The matching step of QueryProcessorBasic (query_processor_basic.cpp:22-53 and :60-96): one float
 // descriptor per 3-D point -- the mean of the descriptors of its views -- and, per query
 // descriptor, the two nearest of them by squared L2 distance with Lowe's ratio test.  The search is
@@ -184,10 +159,17 @@ private:
     Device *dev_;
 };
 
-// The pose-related part of query_loader.hpp:30-75.
+// query_loader.hpp:30-75.  The image itself (cv::Mat, LoadImage) is not part of the path.
+class QueryLoader;
 class Query {
 public:
     Query(int width, int height, double focal_length = 0.0) : focal_(focal_length), w_(width), h_(height)
+    {
+        rot_(0, 0) = rot_(1, 1) = rot_(2, 2) = 1.0;
+    }
+    // query_loader.cpp:84-88: a query of a list, its features are read by LoadSIFT
+    Query(QueryLoader *query_loader, std::string query_image_name, double focal_length)
+        : focal_(focal_length), w_(0), h_(0), loader_(query_loader), name_(std::move(query_image_name))
     {
         rot_(0, 0) = rot_(1, 1) = rot_(2, 2) = 1.0;
     }
@@ -202,7 +184,24 @@ public:
     int image_height() const { return h_; }
     void set_image_width(int w) { w_ = w; }
     void set_image_height(int h) { h_ = h; }
+    const std::string &image_name() const { return name_; }
     std::vector<SIFT_keypoint> &sift_keypoints() { return keys_; }
+    // One pointer per keypoint to its 128 descriptor bytes (query_loader.hpp:47).  The bytes are owned
+    // by the query and shared by its copies, so the pointers of a copy stay valid (the reference
+    // copies queries freely: basic.cpp:59, benchmark.cpp:28).
+    std::vector<unsigned char *> &sift_descriptors() { return desc_; }
+    // Takes over keypoints and their descriptors (128 bytes per keypoint).
+    void set_sift(const std::vector<SIFT_keypoint> &keypoints, const std::vector<unsigned char> &descriptors)
+    {
+        keys_ = keypoints;
+        bytes_ = std::make_shared<std::vector<unsigned char>>(descriptors);
+        bytes_->resize(keys_.size() * 128);
+        desc_.resize(keys_.size());
+        for (size_t i = 0; i < keys_.size(); ++i) desc_[i] = bytes_->data() + i * 128;
+    }
+    // query_loader.cpp:153-177: reads <query_path><name>.key (the reference first tries to gunzip it
+    // from the database directory through system(); this loader reads only).  Defined behind QueryLoader.
+    inline bool LoadSIFT();
     // projections / world points of the fitted matches, filled by Process (query_loader.hpp:76-79)
     std::vector<Vector2d> &fitpoints_2d() { return fit2d_; }
     std::vector<Vector3d> &fitpoints_3d() { return fit3d_; }
@@ -227,20 +226,90 @@ private:
     Matrix3d rot_;
     Mat<3, 4> proj_;
     std::vector<SIFT_keypoint> keys_;
+    std::vector<unsigned char *> desc_;
+    std::shared_ptr<std::vector<unsigned char>> bytes_;
     std::vector<Vector2d> fit2d_;
     std::vector<Vector3d> fit3d_;
     int w_, h_;
+    QueryLoader *loader_ = nullptr;
+    std::string name_;
 };
 
+// query_loader.hpp:77-91, query_loader.cpp:28-82: the list "<database_path>list.query.fused.txt" with
+// one query per line, "query/<name>.jpg <width> <height> [<focal length>]"; the features of query
+// <name> are read from "<query_path><name>.key" when the query is asked for.
+class QueryLoader {
+public:
+    QueryLoader(std::string database_path, std::string query_path) : database_path_(std::move(database_path)), query_path_(std::move(query_path))
+    {
+        std::ifstream queryfile(database_path_ + "list.query.fused.txt");
+        std::string line;
+        while (std::getline(queryfile, line)) {
+            std::vector<std::string> f;
+            size_t pos = 0;
+            while (pos <= line.size()) {
+                const size_t e = line.find(' ', pos);
+                f.push_back(line.substr(pos, e == std::string::npos ? std::string::npos : e - pos));
+                if (e == std::string::npos) break;
+                pos = e + 1;
+            }
+            if (f.size() < 3) continue;
+            const double focal = f.size() == 4 ? std::atof(f[3].c_str()) : 0.0;
+            // the name between the first '/' and the first '.' behind it (CutString, pose_utils.cpp:36-56)
+            const size_t slash = f[0].find('/');
+            const size_t dot = slash == std::string::npos ? std::string::npos : f[0].find('.', slash + 1);
+            if (slash == std::string::npos || dot == std::string::npos || dot == slash + 1) continue;
+            Query query(this, f[0].substr(slash + 1, dot - slash - 1), focal);
+            query.set_image_width(std::atoi(f[1].c_str()));
+            query.set_image_height(std::atoi(f[2].c_str()));
+            queries_.push_back(query);
+        }
+    }
+    std::string database_path() const { return database_path_; }
+    std::string query_path() const { return query_path_; }
+    int GetQueryCount() const { return (int)queries_.size(); }
+    // the features are read when a query is first asked for; load_image is accepted and ignored
+    Query &GetQuery(int index, bool /*load_image*/)
+    {
+        queries_[(size_t)index].LoadSIFT();
+        return queries_[(size_t)index];
+    }
+
+private:
+    std::string database_path_, query_path_;
+    std::vector<Query> queries_;
+};
+
+inline bool Query::LoadSIFT()
+{
+    if (!loader_) return false;
+    SIFT_loader siftl;
+    if (!siftl.load_Lowe_features((loader_->query_path() + name_ + ".key").c_str())) return false;
+    set_sift(siftl.get_keypoints(), siftl.get_descriptors());
+    return true;
+}
+
 // ---- query_processor.hpp:33-73 ------------------------------------------------------------------
-// The matching stage that precedes RANSAC in the reference's Process (FLANN search) is not part
-// of this library: Process takes the `good_matches` list the reference has at basic.cpp:105 /
-// advanced.cpp:296 together with the 3D points they refer to.
+// Two ways in.  A processor built on a parse_bundler, as in the reference (query_processor.hpp:35),
+// averages the model's descriptors and holds them on the device; its Process(Query&) is the
+// reference's: descriptors -> two nearest -> ratio test -> RANSAC.  A processor built without a
+// model takes the `good_matches` list the reference has at basic.cpp:105 / advanced.cpp:296 together
+// with the 3-D points they refer to (the entry for callers with a matching stage of their own).
 class QueryProcessor {
 public:
     explicit QueryProcessor(Device *dev = nullptr) : dev_(dev ? dev : &Device::current()) {}
+    // query_processor_basic.cpp:22-55 / query_processor_advanced.cpp:24-56 (both build the same index)
+    explicit QueryProcessor(parse_bundler &parsebundler, Device *dev = nullptr)
+        : dev_(dev ? dev : &Device::current()), parsebundler_(&parsebundler), sifts_(&parsebundler.get_feature_infos()),
+          matcher_(new DescriptorMatcher(parsebundler.get_feature_infos(), dev_))
+    {
+    }
     virtual ~QueryProcessor() {}
+    // query_processor.hpp:36.  Throws std::logic_error on a processor built without a model.
+    virtual bool Process(Query &query) = 0;
     virtual bool Process(Query &query, std::vector<SiftMatch> &good_matches, std::vector<feature_3D_info> &sifts) = 0;
+    // good_matches of the last Process(Query&)
+    std::vector<SiftMatch> good_matches;
 
     // Reprojection of `matches` with query.proj_matrix() (query_processor.cpp:46-86).
     bool Project(Query &query, std::vector<Vector2d> &fitpoints_2d, std::vector<Vector3d> &fitpoints_3d, std::vector<SiftMatch> &matches,
@@ -372,10 +441,23 @@ protected:
         query.set_fitpoints_2d(fit2d_);
         query.set_fitpoints_3d(fit3d_);
     }
+    // basic.cpp:60-96 / advanced.cpp:242-285: two nearest model descriptors of every query descriptor,
+    // Lowe's ratio test on the squared distances; with_camsets fills SiftMatch::camset from the view lists
+    void match(Query &query, float ratio, bool with_camsets)
+    {
+        if (!matcher_) throw std::logic_error("QueryProcessor::Process(Query&): the processor was built without a parse_bundler");
+        good_matches = matcher_->Match(query.sift_descriptors(), ratio);
+        if (with_camsets)
+            for (SiftMatch &m : good_matches)
+                for (const view &v : (*sifts_)[m.mindex].view_list) m.camset.insert(v.camera);
+    }
     std::vector<Vector2d> fit2d_;
     std::vector<Vector3d> fit3d_;
     Device *dev_;
     double solver_focal_ = 0.0;             // focal length the query came with: 0 selects P4Pf (basic.cpp:154)
+    parse_bundler *parsebundler_ = nullptr;
+    std::vector<feature_3D_info> *sifts_ = nullptr;
+    std::shared_ptr<DescriptorMatcher> matcher_;
 };
 
 class QueryProcessorBasic : public QueryProcessor {
@@ -383,6 +465,13 @@ public:
     using QueryProcessor::QueryProcessor;
     uint32_t max_ransac_steps = 10000;
     std::vector<int> devices;    // ProcessBatch: GPUs to spread the queries over (empty: this processor's device only)
+    float ratio = 0.7f;          // basic.cpp:87
+    // query_processor_basic.cpp:57-310
+    bool Process(Query &query) override
+    {
+        match(query, ratio, false);
+        return Process(query, good_matches, *sifts_);
+    }
     // query_processor_basic.cpp:105-293
     bool Process(Query &query, std::vector<SiftMatch> &good_matches, std::vector<feature_3D_info> &sifts) override
     {
@@ -468,6 +557,13 @@ public:
     void *backmatching_user = nullptr;
     int best_leg = 0;            // which leg kept the pose (0: before, 1: after backmatching); result.best_hyp counts within it
     bool backmatched = false;    // the second leg ran
+    float ratio = 0.9f;          // advanced.cpp:269
+    // query_processor_advanced.cpp:239-624
+    bool Process(Query &query) override
+    {
+        match(query, ratio, true);
+        return Process(query, good_matches, *sifts_);
+    }
     // query_processor_advanced.cpp:296-606
     bool Process(Query &query, std::vector<SiftMatch> &good_matches, std::vector<feature_3D_info> &sifts) override
     {

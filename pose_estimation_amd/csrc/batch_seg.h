@@ -60,9 +60,11 @@ __device__ __forceinline__ const seg_query &seg_of(const seg_launch &L, int p) {
 __global__ __launch_bounds__(COVSEL_THREADS) void k_seg_compact(const seg_query *__restrict__ qt, const int *__restrict__ cand, int ncand,
                                                                  const unsigned long long *__restrict__ state, int early_exit,
                                                                  int *__restrict__ active, int *__restrict__ n_active, int steps,
-                                                                 unsigned long long *__restrict__ steps_issued)
+                                                                 unsigned long long *__restrict__ steps_issued, unsigned int *__restrict__ zero, int nzero)
 {
     __shared__ int s_tmp[COVSEL_THREADS / 64];
+    if (zero)                                                                      // counters the round's first pass starts from (null: none)
+        for (int i = threadIdx.x; i < nzero; i += COVSEL_THREADS) zero[i] = 0u;
     int n = 0;
     for (int base = 0; base < ncand; base += COVSEL_THREADS) {
         const int i = base + threadIdx.x;
@@ -166,7 +168,7 @@ __global__ void k_seg_make_feat(const seg_query *__restrict__ qt)
 // query: vlist[segment of the query], vcount[position] (zeroed before the launch); the counts of
 // the other slots are set to 0.
 __global__ __launch_bounds__(256) void k_seg_compact_valid(seg_launch L, int maxsol, const int *__restrict__ nsol, int *__restrict__ vlist,
-                                                            unsigned int *__restrict__ vcount, int *__restrict__ counts)
+                                                            unsigned int *__restrict__ vcount, int *__restrict__ counts, int zero_all)
 {
     __shared__ int s_n[4];
     __shared__ unsigned s_base;
@@ -183,7 +185,7 @@ __global__ __launch_bounds__(256) void k_seg_compact_valid(seg_launch L, int max
         const int slot = slot0 + 256 * k;
         const bool ok = slot < nslots && (slot % maxsol) < nsol[base + slot / maxsol];
         if (ok) valid |= 1u << k;
-        if (slot < nslots && !ok) counts[sbase + slot] = 0;
+        if (slot < nslots && (!ok || zero_all)) counts[sbase + slot] = 0;     // zero_all: the scoring blocks add their shares
     }
     const int mine = __popc(valid);
     int incl = mine;
@@ -206,20 +208,35 @@ __global__ __launch_bounds__(256) void k_seg_compact_valid(seg_launch L, int max
 // k_score_mfma for the queries of a pass: blockIdx.y = position, blockIdx.x = batch of 64 WAVES valid
 // poses of that query.  Blocks are small (two or four waves) because a round of 64 steps gives a
 // query about a hundred valid poses.
+// gridDim.z > 1: up to that many blocks share a batch of poses along the correspondences and add
+// their counts (zeroed by k_seg_compact_valid).  How many do is decided here, per query, from the
+// length of the list of running queries: a short list is a chain of latencies -- a block's walk over
+// all tiles of its query -- and gets its blocks cut until about `target_blocks` of them work; a long
+// list fills the chip with whole-range blocks.
 template <int WAVES, int CHUNK>
 __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_seg_score_mfma(seg_launch L, int maxsol, const double *__restrict__ proj,
                                                                                                           const int *__restrict__ vlist,
                                                                                                           const unsigned int *__restrict__ vcount, double eps,
-                                                                                                          int *__restrict__ counts)
+                                                                                                          int *__restrict__ counts, int target_blocks)
 {
     const int a = blockIdx.y;
     if (!seg_live(L, a)) return;
     const int nvalid = (int)vcount[a], first = (int)blockIdx.x * (WAVES * 64);
     if (first >= nvalid) return;
+    int nshare = 1;
+    if (gridDim.z > 1) {
+        const int running = min(*L.n_active - L.a0, (int)gridDim.y);
+        const int blocks = (nvalid + WAVES * 64 - 1) / (WAVES * 64);
+        nshare = max(1, min((int)gridDim.z, target_blocks / max(1, running * blocks)));
+        if ((int)blockIdx.z >= nshare) return;
+    }
     const seg_query &sq = seg_of(L, a);
     const size_t sbase = (size_t)a * L.S * maxsol;
-    score_mfma_core<WAVES, CHUNK>(sq.q, sq.qc, sq.feat, 0, (sq.q.n + 31) / 32, 1, 0, proj + sbase * 12, vlist + sbase, nvalid, first, eps, counts + sbase, nullptr,
-                                  nullptr);
+    const int ntiles = (sq.q.n + 31) / 32, share = (ntiles + nshare - 1) / nshare;
+    const int tile_begin = (int)blockIdx.z * share, tile_end = min(ntiles, tile_begin + share);
+    if (tile_begin >= tile_end) return;
+    score_mfma_core<WAVES, CHUNK>(sq.q, sq.qc, sq.feat, tile_begin, tile_end, gridDim.z > 1 ? 2 : 1, 0, proj + sbase * 12, vlist + sbase, nvalid, first, eps,
+                                  counts + sbase, nullptr, nullptr);
 }
 
 // ---- coverage-quality selection, one block per query -----------------------------------------------

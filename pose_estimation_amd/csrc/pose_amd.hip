@@ -29,7 +29,9 @@ constexpr size_t NOALLOC_SCRATCH_BYTES = NOALLOC_STATUS_OFFSET + (size_t)NOALLOC
 static __device__ __align__(256) unsigned char scratch[NOALLOC_SCRATCH_BYTES];
 
 namespace {
-std::string g_create_error;
+std::string g_create_error;          // guarded by g_create_error_lock
+std::mutex g_create_error_lock;
+void set_create_error(const std::string &msg) { std::lock_guard<std::mutex> g(g_create_error_lock); g_create_error = msg; }
 constexpr int MAX_DEVICES = 64;
 std::mutex g_noalloc_lock;
 void *g_noalloc_scratch[MAX_DEVICES] = {nullptr};   // device address of `scratch` on each GPU
@@ -226,19 +228,19 @@ extern "C" {
 
 int pose_amd_create(int device, pose_amd_ctx **out)
 {
-    if (!out) { g_create_error = "out is NULL"; return POSE_AMD_EINVAL; }
+    if (!out) { set_create_error("out is NULL"); return POSE_AMD_EINVAL; }
     *out = nullptr;
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
     if (e != hipSuccess || ndev <= 0) {
-        g_create_error = std::string("no HIP device available: ") + hipGetErrorString(e);
+        set_create_error(std::string("no HIP device available: ") + hipGetErrorString(e));
         return POSE_AMD_EHIP;
     }
-    if (device < 0 || device >= ndev) { g_create_error = "device index out of range"; return POSE_AMD_EINVAL; }
+    if (device < 0 || device >= ndev) { set_create_error("device index out of range"); return POSE_AMD_EINVAL; }
     pose_amd_ctx *c = new pose_amd_ctx();
     c->device = device;
     auto bail = [&](const char *what, hipError_t er) {
-        g_create_error = std::string(what) + ": " + hipGetErrorString(er);
+        set_create_error(std::string(what) + ": " + hipGetErrorString(er));
         delete c;
         return POSE_AMD_EHIP;
     };
@@ -309,7 +311,15 @@ void pose_amd_destroy(pose_amd_ctx *c)
     delete c;
 }
 
-const char *pose_amd_last_error(const pose_amd_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+const char *pose_amd_last_error(const pose_amd_ctx *ctx)
+{
+    if (ctx) return ctx->err.c_str();
+    // a copy per calling thread: the shared string may be rewritten by a creation failing on another thread
+    static thread_local std::string copy;
+    std::lock_guard<std::mutex> g(g_create_error_lock);
+    copy = g_create_error;
+    return copy.c_str();
+}
 
 int pose_amd_device_info(const pose_amd_ctx *ctx, char *name, int name_len, int *compute_units, int *clock_khz)
 {
@@ -518,7 +528,7 @@ int pose_amd_set_camsets(pose_amd_ctx *ctx, const uint32_t *cam_off, const uint3
     if ((rc = upload(ctx, ctx->cam_off, cam_off, ((size_t)ctx->n + 1) * 4))) return rc;
     const size_t total = cam_off[ctx->n];
     // 16 bytes of slack: the sampler reads a set four words at a time
-    if ((rc = ensure(ctx, ctx->cam_ids, (total ? total : 1) * 4 + 16)) || (rc = upload(ctx, ctx->cam_ids, cam_ids, (total ? total : 1) * 4))) return rc;
+    if ((rc = ensure(ctx, ctx->cam_ids, total * 4 + 16)) || (rc = upload(ctx, ctx->cam_ids, cam_ids, total * 4))) return rc;   // total >= 5 here
     ctx->has_cam = true;
     ctx->cam_max = cam_max;
     return pose_amd_synchronize(ctx);
@@ -545,7 +555,7 @@ int pose_amd_compute_matrices_batch(pose_amd_ctx *ctx, int count, const double *
 // (early-exit chunks, single poses) keep the packed-float32 kernel, whose blocks adapt to them.
 static bool use_mfma_screen(const pose_amd_ctx *ctx, int nslots, bool want_masks)
 {
-    static const int min_slots = getenv("POSE_AMD_MFMA_MIN_SLOTS") ? atoi(getenv("POSE_AMD_MFMA_MIN_SLOTS")) : 8192;
+    const int min_slots = getenv("POSE_AMD_MFMA_MIN_SLOTS") ? atoi(getenv("POSE_AMD_MFMA_MIN_SLOTS")) : 8192;
     return ctx->score_mfma && !ctx->score_fp64_only && !want_masks && nslots >= min_slots && ctx->n <= MS_MAX_N - 32 &&
            ctx->centre.xmaxc == ctx->centre.xmaxc && ctx->umax == ctx->umax;
 }
@@ -1316,12 +1326,12 @@ static int batch_fill(pose_amd_ctx *ctx, pose_amd_batch *b, int nq, const pose_a
                 {   // one block per pose where the query fits it: rows per pass from 76 KB of LDS, the most that leaves
                     // two blocks on a compute unit (fewer, taller passes: 60 KB measured 5 % slower for the advanced batch)
                     const int W = (q.width + 63) / 64, h2 = 2 * ((int)std::ceil((float)q.width / 20.0f) / 2);
-                    static const int cover_kb = getenv("POSE_AMD_SEG_COVER_KB") ? std::max(16, std::min(150, atoi(getenv("POSE_AMD_SEG_COVER_KB")))) : 76;
+                    const int cover_kb = getenv("POSE_AMD_SEG_COVER_KB") ? std::max(16, std::min(150, atoi(getenv("POSE_AMD_SEG_COVER_KB")))) : 76;
                     const int rows_total = (cover_kb * 1024) / (8 * W);
                     const int nhp = (rows_total * 8 / 9) & ~7;
                     int rb = (nhp - 8 - (h2 - 1)) & ~7;
                     rb = std::min(rb, (q.height + 7) & ~7);
-                    static const bool off = getenv("POSE_AMD_SEG_COVER") && strcmp(getenv("POSE_AMD_SEG_COVER"), "bands") == 0;
+                    const bool off = getenv("POSE_AMD_SEG_COVER") && strcmp(getenv("POSE_AMD_SEG_COVER"), "bands") == 0;
                     sq.cv_rows = (!off && q.n <= CVP_THREADS * CVP_KM && h2 >= 8 && rb >= 8 && q.width <= 16384 && q.height <= 16384 &&
                                   cdiv(q.height, std::max(rb, 1)) <= CVP_PASSES) ? rb : 0;
                     if (sq.cv_rows) {
@@ -1515,7 +1525,10 @@ static int batch_run_segmented(pose_amd_batch *b, int sample_mode, uint64_t seed
     // query's last one is wasted: rounds start short (128 steps) and grow fivefold -- few enough rounds
     // that the small launches of the late ones, which are all latency, do not add up (measured on the
     // Dubrovnik-shaped batch: 64,2 / 128,3 / 128,5 / 128,8 give 80 / 93 / 97 / 83 thousand queries per second).
-    uint32_t first_len = 128u, growth = 5u;
+    // A short list leaves the chip mostly idle, so its wasted steps cost little and its rounds, each a chain
+    // of about twenty dependent launches, cost everything: it starts with 256 steps (100 queries: 2.04 -> 1.75 ms
+    // per pass; 800 queries: 4.9 -> 5.3 ms, so long lists keep 128).
+    uint32_t first_len = nlive < 300 ? 256u : 128u, growth = 5u;
     if (const char *e = getenv("POSE_AMD_SEG_ROUNDS")) {
         unsigned a1 = 0, a2 = 0;
         if (sscanf(e, "%u,%u", &a1, &a2) == 2 && a1 >= 16 && a2 >= 2) { first_len = std::min(a1, 16384u); growth = std::min(a2, 16u); }
@@ -1525,11 +1538,11 @@ static int batch_run_segmented(pose_amd_batch *b, int sample_mode, uint64_t seed
     size_t pass_bytes = (size_t)4 << 30;
     if (const char *e = getenv("POSE_AMD_SEG_PASS_MB")) pass_bytes = (size_t)std::max(16, atoi(e)) << 20;
     const int bands_max = b->bands_max;
-    static const bool seg_packed = getenv("POSE_AMD_SEG_SCORE") && strcmp(getenv("POSE_AMD_SEG_SCORE"), "packed") == 0;
+    const bool seg_packed = getenv("POSE_AMD_SEG_SCORE") && strcmp(getenv("POSE_AMD_SEG_SCORE"), "packed") == 0;
     // The matrix-core screen pays where nearly all poses are junk (the random tuples of the basic
     // sampler); the co-occurrence sampler returns many poses with hundreds of inliers, whose pairs
     // the screen cannot certify, and the packed float32 screen is the faster one there.
-    static const bool seg_mfma_always = getenv("POSE_AMD_SEG_SCORE") && strcmp(getenv("POSE_AMD_SEG_SCORE"), "mfma") == 0;
+    const bool seg_mfma_always = getenv("POSE_AMD_SEG_SCORE") && strcmp(getenv("POSE_AMD_SEG_SCORE"), "mfma") == 0;
     const bool use_mfma = b->mfma_ok && !seg_packed && (!advanced || seg_mfma_always);
     // blocks per (query, band) of the two coverage launches of a pass (records, candidates): every block
     // scans the query's correspondences once, so few blocks with several poses each
@@ -1541,6 +1554,9 @@ static int batch_run_segmented(pose_amd_batch *b, int sample_mode, uint64_t seed
         if (sscanf(e, "%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3]) == 4 && v[0] > 0 && v[1] > 0 && v[2] > 0 && v[3] > 0)
             for (int i = 0; i < 4; ++i) pose_blocks[i] = std::min(v[i], 1024);
     }
+    // matrix-core scoring: most blocks that may share a batch of poses along the correspondences (1: whole-range blocks only)
+    int seg_shares = 8;
+    if (const char *e = getenv("POSE_AMD_SEG_SCORE_SHARES")) seg_shares = std::max(1, std::min(16, atoi(e)));
     int cov_blocks[2] = {1, 2};
     if (const char *e = getenv("POSE_AMD_SEG_COV_BLOCKS")) {
         int a1 = 0, a2 = 0;
@@ -1570,12 +1586,15 @@ static int batch_run_segmented(pose_amd_batch *b, int sample_mode, uint64_t seed
             const int maxsol = solver ? P4PF_MAXSOL : P3P_MAXSOL;
             pose_amd_ctx::seg_scratch &G = ctx->sgs[solver];
             hipStream_t stream = streams[solver];
-            hipLaunchKernelGGL(k_seg_compact, dim3(1), dim3(COVSEL_THREADS), 0, stream, (const seg_query *)b->qtab.p, (const int *)cand_dev[solver],
-                               nsolver[solver], (const unsigned long long *)b->state.p, early ? 1 : 0, active_dev[solver], nact_dev[solver], (int)valid, issued_dev + solver);
-            if ((rc = mark(6))) return rc;
             const size_t per_hyp = (size_t)maxsol * (96 + 104 + 128 + 4) + 16 + 4 + 4 + (solver ? P4PF_TAIL * 8 + 4 : 0);
             // after the first round only queries that did not end in it are left: at most all of them
             const int per_pass = (int)std::max<size_t>(1, std::min<size_t>((size_t)nsolver[solver], std::min<size_t>(32768, pass_bytes / ((size_t)S * per_hyp))));
+            // the list kernel also zeroes the first pass's counters of valid pose slots (one launch less per round)
+            if (use_mfma && (rc = ensure(ctx, G.vcount, (size_t)per_pass * 4))) return rc;
+            hipLaunchKernelGGL(k_seg_compact, dim3(1), dim3(COVSEL_THREADS), 0, stream, (const seg_query *)b->qtab.p, (const int *)cand_dev[solver],
+                               nsolver[solver], (const unsigned long long *)b->state.p, early ? 1 : 0, active_dev[solver], nact_dev[solver], (int)valid, issued_dev + solver,
+                               use_mfma ? (unsigned int *)G.vcount.p : nullptr, use_mfma ? per_pass : 0);
+            if ((rc = mark(6))) return rc;
             for (int a0 = 0; a0 < nsolver[solver]; a0 += per_pass) {
                 const size_t na = (size_t)std::min(per_pass, nsolver[solver] - a0), nh = na * S, ns = nh * maxsol;
                 if ((rc = ensure(ctx, G.samples, nh * 16)) || (rc = ensure(ctx, G.sstatus, nh * 4)) || (rc = ensure(ctx, G.proj, ns * 96)) ||
@@ -1616,18 +1635,24 @@ static int batch_run_segmented(pose_amd_batch *b, int sample_mode, uint64_t seed
                 }
                 if (use_mfma) {
                     // the matrix-core screen: list of the valid slots of every query, then blocks of two waves (128 poses)
-                    if ((rc = ensure(ctx, G.vlist, ns * 4)) || (rc = ensure(ctx, G.vcount, na * 4))) return rc;
-                    HIPCHK(ctx, hipMemsetAsync(G.vcount.p, 0, na * 4, stream));
-                    hipLaunchKernelGGL(k_seg_compact_valid, dim3(cdiv((long long)valid * maxsol, MS_COMPACT_SLOTS), (unsigned)na), dim3(256), 0, stream, L, maxsol,
-                                       (const int *)nsol, (int *)G.vlist.p, (unsigned int *)G.vcount.p, counts);
+                    if ((rc = ensure(ctx, G.vlist, ns * 4))) return rc;
+                    if (a0 > 0) HIPCHK(ctx, hipMemsetAsync(G.vcount.p, 0, na * 4, stream));      // the first pass's were zeroed by k_seg_compact
                     // long rounds give a query thousands of valid poses: the block shape of the per-query kernel (8 waves, 512 poses)
-                    if (valid >= 2048)
-                        hipLaunchKernelGGL((k_seg_score_mfma<MS_WAVES, MS_CHUNK_TILES>), dim3(cdiv((long long)valid * maxsol, MS_POSES), (unsigned)na), dim3(MS_THREADS), 0,
-                                           stream, L, maxsol, (const double *)proj, (const int *)G.vlist.p, (const unsigned int *)G.vcount.p, prm->eps, counts);
+                    const bool big = valid >= 2048;
+                    const long long bx = cdiv((long long)valid * maxsol, big ? MS_POSES : SEG_MFMA_WAVES * 64);
+                    // blocks that may share a batch of poses along the correspondences (the kernel decides how many do, from the
+                    // number of running queries); bounded so that a long list's launch does not grow by blocks that only leave
+                    const unsigned shares = (unsigned)std::max<long long>(1, std::min<long long>(seg_shares, 8192 / std::max<long long>(1, bx * (long long)na)));
+                    hipLaunchKernelGGL(k_seg_compact_valid, dim3(cdiv((long long)valid * maxsol, MS_COMPACT_SLOTS), (unsigned)na), dim3(256), 0, stream, L, maxsol,
+                                       (const int *)nsol, (int *)G.vlist.p, (unsigned int *)G.vcount.p, counts, shares > 1 ? 1 : 0);
+                    const int target_blocks = 2 * (ctx->cus ? ctx->cus : 256);
+                    if (big)
+                        hipLaunchKernelGGL((k_seg_score_mfma<MS_WAVES, MS_CHUNK_TILES>), dim3((unsigned)bx, (unsigned)na, shares), dim3(MS_THREADS), 0,
+                                           stream, L, maxsol, (const double *)proj, (const int *)G.vlist.p, (const unsigned int *)G.vcount.p, prm->eps, counts, target_blocks);
                     else
-                        hipLaunchKernelGGL((k_seg_score_mfma<SEG_MFMA_WAVES, SEG_MFMA_CHUNK>), dim3(cdiv((long long)valid * maxsol, SEG_MFMA_WAVES * 64), (unsigned)na),
+                        hipLaunchKernelGGL((k_seg_score_mfma<SEG_MFMA_WAVES, SEG_MFMA_CHUNK>), dim3((unsigned)bx, (unsigned)na, shares),
                                            dim3(SEG_MFMA_WAVES * 64), 0, stream, L, maxsol, (const double *)proj, (const int *)G.vlist.p,
-                                           (const unsigned int *)G.vcount.p, prm->eps, counts);
+                                           (const unsigned int *)G.vcount.p, prm->eps, counts, target_blocks);
                 } else {
                     // slots per block as in launch_score: as many as possible while the launch keeps about four blocks per compute unit
                     int spb = SCORE_SPB;
@@ -1809,7 +1834,7 @@ static int ransac_batch_threads(pose_amd_ctx *ctx, int nq, const pose_amd_query 
 // Many queries per launch; POSE_AMD_BATCH=threads takes one launch sequence per query on worker threads.
 static bool batch_shares_launches(int sample_mode, const pose_amd_params *prm)
 {
-    static const bool off = getenv("POSE_AMD_BATCH") && strcmp(getenv("POSE_AMD_BATCH"), "threads") == 0;
+    const bool off = getenv("POSE_AMD_BATCH") && strcmp(getenv("POSE_AMD_BATCH"), "threads") == 0;
     return !off && (prm->select_mode == POSE_AMD_SELECT_COVERAGE || prm->select_mode == POSE_AMD_SELECT_INLIERS) && prm->eps > 0 &&
            prm->inlier_divisor != 0 && (sample_mode == POSE_AMD_SAMPLE_BASIC || sample_mode == POSE_AMD_SAMPLE_ADVANCED);
 }
@@ -1921,7 +1946,8 @@ int pose_amd_knn_set_model_views(pose_amd_ctx *ctx, int npoints, const uint32_t 
     ctx->knn_points = 0;
     int rc;
     const size_t nd = desc_off[npoints];
-    if ((rc = upload(ctx, ctx->knn_in0, desc_off, ((size_t)npoints + 1) * 4)) || (rc = upload(ctx, ctx->knn_in1, descriptors, std::max<size_t>(nd, 1) * KNN_DIM)) ||
+    if (nd == 0) return fail(ctx, POSE_AMD_EINVAL, "knn_set_model_views: no point has a view descriptor");
+    if ((rc = upload(ctx, ctx->knn_in0, desc_off, ((size_t)npoints + 1) * 4)) || (rc = upload(ctx, ctx->knn_in1, descriptors, nd * KNN_DIM)) ||
         (rc = ensure(ctx, ctx->knn_feat, (size_t)npoints * KNN_DIM * 4)))
         return rc;
     hipLaunchKernelGGL(k_knn_average, dim3(npoints), dim3(KNN_DIM), 0, ctx->stream, npoints, (const unsigned int *)ctx->knn_in0.p,

@@ -205,12 +205,11 @@ __device__ __forceinline__ void ms_prepare(const double *__restrict__ proj, int 
     o.c = cf;
 }
 
-// The float64 decision of k_score for one (pose, correspondence) pair.
-__device__ __forceinline__ bool ms_exact_inlier(const query_dev &q, const double *__restrict__ proj, int slot, int idx, double eps)
+// The float64 decision of k_score for one (pose, correspondence) pair, the pose's matrix in registers.
+__device__ __forceinline__ bool ms_exact_inlier_p(const query_dev &q, const double (&P)[12], int idx, double eps)
 {
     if (idx >= q.n) return false;
     const double hw = (double)q.width / 2.0, hh = (double)q.height / 2.0;
-    const double *__restrict__ P = proj + (size_t)slot * 12;
     const double u = -((double)q.kx[idx] - hw), v = -((double)q.ky[idx] - hh);
     const double X = (double)q.X[idx], Y = (double)q.Y[idx], Z = (double)q.Z[idx];
     const double px = fma(P[0], X, fma(P[1], Y, fma(P[2], Z, P[3])));
@@ -220,6 +219,13 @@ __device__ __forceinline__ bool ms_exact_inlier(const query_dev &q, const double
     const double d2 = fma(ry, ry, rx * rx);
     const double te = eps * pz;
     return d2 < te * te;
+}
+__device__ __forceinline__ bool ms_exact_inlier(const query_dev &q, const double *__restrict__ proj, int slot, int idx, double eps)
+{
+    double P[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) P[i] = proj[(size_t)slot * 12 + i];
+    return ms_exact_inlier_p(q, P, idx, eps);
 }
 
 // counts[slot] for the valid slots listed in vlist[0 .. nvalid).  One block takes POSES = 64 WAVES
@@ -373,20 +379,37 @@ __device__ __forceinline__ void score_mfma_core(const query_dev &q, const query_
     }
     __builtin_amdgcn_wave_barrier();
     drain(qn);
+    __syncthreads();
     {
-        // the poses that left the screen: float64 test of their remaining correspondences, 64 at a time
-        const int dstart = s_dense[wave * (32 * MS_GROUPS) + lane];
+        // The poses that left the screen: float64 test of their remaining correspondences by the whole
+        // block, pose after pose, four independent tests per thread and turn (a turn is one memory
+        // latency; a wave alone on its own poses spent most of a small launch here).
+        int *s_dlist = reinterpret_cast<int *>(s_feat);          // the chunk buffer is free by now
+        int *s_dn = s_dlist + POSES;
         const int dend = min(q.n, tile_end * 32);
-        unsigned long long dm = __ballot(dstart < dend);
-        while (dm) {
-            const int l = __builtin_ctzll(dm);
-            dm &= dm - 1;
-            const int pl = wave * (32 * MS_GROUPS) + l;
-            const int slot = s_slot[pl];
-            int total = 0;
-            for (int base = __builtin_amdgcn_readlane(dstart, l); base < dend; base += 64)
-                total += __popcll(__ballot(base + lane < dend && ms_exact_inlier(q, proj, slot, base + lane, eps)));
-            if (lane == 0) atomicAdd(&s_cnt[pl], total);
+        if (tid == 0) *s_dn = 0;
+        __syncthreads();
+        if (s_dense[tid] < dend) s_dlist[atomicAdd(s_dn, 1)] = tid;
+        __syncthreads();
+        const int dn = *s_dn;
+        for (int k = 0; k < dn; ++k) {
+            const int pl = s_dlist[k];
+            const int slot = s_slot[pl], dstart = s_dense[pl];
+            double P[12];
+#pragma unroll
+            for (int i = 0; i < 12; ++i) P[i] = proj[(size_t)slot * 12 + i];
+            int total = 0;                                        // wave-uniform
+            for (int b0 = __builtin_amdgcn_readfirstlane(dstart) + wave * 64; b0 < dend; b0 += 4 * THREADS) {
+                bool in[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int idx = b0 + j * THREADS + lane;
+                    in[j] = idx < dend && ms_exact_inlier_p(q, P, idx, eps);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) total += (int)__popcll(__ballot(in[j]));
+            }
+            if (lane == 0 && total) atomicAdd(&s_cnt[pl], total);
         }
     }
     __syncthreads();

@@ -3,8 +3,11 @@
 // two processors on a synthetic query with a planted pose.  Exit status 0 = all checks passed.
 #include <cmath>
 #include <cstdio>
+#include <algorithm>
 #include <cstdlib>
+#include <iomanip>
 #include <random>
+#include <string>
 
 #include "pose_amd.hpp"
 #include "pose_amd_io.hpp"
@@ -400,8 +403,137 @@ static void test_matching()
     CHECK(g == good.size() && expected_good >= 20 && expected_good <= 40);
 }
 
-int main()
+// The reference's own call sequence (pose_estimation.cpp:72-98, 139, 158): a Bundler file and Lowe
+// .key files on disk -> parse_bundler -> QueryProcessor(parse_bundler&) -> QueryLoader ->
+// qp->Process(query) with nothing else handed over, and Benchmark(ql, golden_pb, qp).  The pose must
+// be the one the pre-matched entry gives on DescriptorMatcher::Match's list.
+static void write_key(const std::string &path, const std::vector<SIFT_keypoint> &keys, const std::vector<unsigned char> &desc)
 {
+    std::ofstream f(path);
+    f << keys.size() << " 128\n";
+    for (size_t i = 0; i < keys.size(); ++i) {
+        f << keys[i].y << " " << keys[i].x << " 1.5 0.25\n";            // Lowe: y before x
+        for (int j = 0; j < 128; ++j) f << " " << (int)desc[i * 128 + j] << ((j % 20 == 19) ? "\n" : "");
+        f << "\n";
+    }
+}
+
+static void test_process_query_only(const std::string &dir)
+{
+    const int w = 1600, h = 1200, ncam = 12, npts = 1200, ninl = 240, nwrong = 100, nrandom = 60;
+    const double f = 1200.0, C[3] = {3.0, -2.0, 1.0};
+    std::mt19937 rng(2024);
+    std::uniform_real_distribution<double> u(-1.0, 1.0);
+    std::uniform_int_distribution<int> byte(0, 90), jitter(-3, 3);
+    auto noisy = [&](const std::vector<int> &proto, std::vector<unsigned char> &out) {
+        for (int j = 0; j < 128; ++j) out.push_back((unsigned char)std::max(0, std::min(255, proto[(size_t)j] + jitter(rng))));
+    };
+    // model: points in front of the planted camera, 2-6 views each, one .key file per camera
+    std::vector<std::vector<int>> proto((size_t)npts, std::vector<int>(128));
+    std::vector<std::vector<SIFT_keypoint>> cam_keys((size_t)ncam);
+    std::vector<std::vector<unsigned char>> cam_desc((size_t)ncam);
+    std::ofstream bundle(dir + "/model.out");
+    bundle << "# Bundle file v0.3\n" << ncam + 1 << " " << npts << "\n";
+    for (int c = 0; c < ncam; ++c) bundle << "1000 0 0\n1 0 0\n0 1 0\n0 0 1\n0 0 0\n";
+    // the query's own camera as the reconstruction knows it (Bundler looks down -Z): R = diag(-1,1,-1), t = -R C
+    bundle << std::setprecision(17) << f << " 0 0\n-1 0 0\n0 1 0\n0 0 -1\n" << C[0] << " " << -C[1] << " " << C[2] << "\n";
+    std::vector<float> px((size_t)npts), py((size_t)npts);
+    for (int i = 0; i < npts; ++i) {
+        for (int &v : proto[(size_t)i]) v = byte(rng);
+        const double z = 10.0 + 95.0 * (u(rng) + 1.0);
+        const double ix = 0.45 * w * u(rng), iy = 0.45 * h * u(rng);
+        const float X = (float)(C[0] + ix * z / f), Y = (float)(C[1] + iy * z / f), Z = (float)(C[2] + z);
+        px[(size_t)i] = (float)(w / 2.0 - ix); py[(size_t)i] = (float)(h / 2.0 - iy);        // keypoint of an exact observation
+        const int nv = i % 9 == 0 ? 6 : 2 + (int)(rng() % 3);
+        bundle << std::setprecision(9) << X << " " << Y << " " << Z << "\n128 128 128\n" << nv;
+        for (int k = 0; k < nv; ++k) {
+            const int c = (i + 5 * k) % ncam;                                             // distinct cameras for nv <= 6
+            bundle << " " << c << " " << cam_keys[(size_t)c].size() << " 0 0";
+            cam_keys[(size_t)c].push_back(SIFT_keypoint());
+            noisy(proto[(size_t)i], cam_desc[(size_t)c]);
+        }
+        bundle << "\n";
+    }
+    bundle.close();
+    std::vector<std::string> key_files;
+    for (int c = 0; c < ncam; ++c) {
+        key_files.push_back(dir + "/cam" + std::to_string(c) + ".key");
+        write_key(key_files.back(), cam_keys[(size_t)c], cam_desc[(size_t)c]);
+    }
+    key_files.push_back(dir + "/no_such_file.key");                                       // nobody's view names the query camera
+    // the query: inliers observe their point, wrong matches carry a model descriptor at a random place, the rest is noise
+    std::vector<SIFT_keypoint> qkeys;
+    std::vector<unsigned char> qdesc;
+    for (int i = 0; i < ninl + nwrong + nrandom; ++i) {
+        SIFT_keypoint k;
+        if (i < ninl) { k.x = px[(size_t)(3 * i)]; k.y = py[(size_t)(3 * i)]; noisy(proto[(size_t)(3 * i)], qdesc); }
+        else {
+            k.x = (float)(w / 2.0 + 0.5 * w * u(rng)); k.y = (float)(h / 2.0 + 0.5 * h * u(rng));
+            if (i < ninl + nwrong) noisy(proto[(size_t)(3 * (i - ninl) + 1)], qdesc);
+            else for (int j = 0; j < 128; ++j) qdesc.push_back((unsigned char)byte(rng));
+        }
+        qkeys.push_back(k);
+    }
+    write_key(dir + "/q0.key", qkeys, qdesc);
+    { std::ofstream l(dir + "/list.query.fused.txt"); l << "query/q0.jpg " << w << " " << h << "\n"; }          // no focal length: P4Pf
+    {
+        std::ofstream l(dir + "/list.orig.txt");
+        for (int c = 0; c < ncam; ++c) l << "db/c" << c << ".jpg 0 1000\n";
+        l << "query/q0.jpg 0 " << f << "\n";
+    }
+
+    parse_bundler pb;
+    CHECK(pb.parse_data((dir + "/model.out").c_str()));
+    CHECK(pb.load_descriptors(key_files));
+    CHECK(pb.get_feature_infos().size() == (size_t)npts && pb.get_feature_infos()[0].view_list.size() == 6);
+    QueryLoader ql(dir + "/", dir + "/");
+    CHECK(ql.GetQueryCount() == 1);
+    for (int advanced = 0; advanced < 2; ++advanced) {
+        QueryProcessorBasic basic(pb);
+        QueryProcessorAdvanced adv(pb);
+        QueryProcessor *qp = advanced ? (QueryProcessor *)&adv : (QueryProcessor *)&basic;      // the reference's `QueryProcessor *qp`
+        qp->seed = 31;
+        Query query = ql.GetQuery(0, false);
+        CHECK(query.image_width() == w && query.focal_length() == 0.0 && query.sift_descriptors().size() == qkeys.size());
+        CHECK(qp->Process(query));                                                      // pose_estimation.cpp:139
+        CHECK(qp->result.found == 1 && qp->result.inliers >= (advanced ? 100u : 12u));
+        // the match list: every inlier and every wrong match passes the ratio test, noise does not
+        CHECK(qp->good_matches.size() >= (size_t)(ninl + nwrong) && qp->good_matches.size() <= (size_t)(ninl + nwrong + 5));
+        CHECK(qp->good_matches[0].lindex == 0 && qp->good_matches[0].mindex == 0 && qp->good_matches[1].mindex == 3);
+        if (advanced) CHECK(qp->good_matches[0].camset.size() == 6 && qp->good_matches[1].camset == pb.camset(3));
+        else CHECK(qp->good_matches[0].camset.empty());
+        const Vector3d Cq = query.camera_position();
+        CHECK(std::sqrt((Cq(0, 0) - C[0]) * (Cq(0, 0) - C[0]) + (Cq(1, 0) - C[1]) * (Cq(1, 0) - C[1]) + (Cq(2, 0) - C[2]) * (Cq(2, 0) - C[2])) < 3.0);
+        // the pre-matched entry on the matcher's own list: the identical pose
+        DescriptorMatcher matcher(pb.get_feature_infos());
+        Query again = ql.GetQuery(0, false);
+        std::vector<SiftMatch> good = matcher.Match(again.sift_descriptors(), advanced ? 0.9f : 0.7f);
+        if (advanced) for (SiftMatch &m : good) m.camset = pb.camset(m.mindex);
+        CHECK(good.size() == qp->good_matches.size());
+        QueryProcessorBasic pre_basic;
+        QueryProcessorAdvanced pre_adv;
+        QueryProcessor *pre = advanced ? (QueryProcessor *)&pre_adv : (QueryProcessor *)&pre_basic;
+        pre->seed = 31;
+        CHECK(pre->Process(again, good, pb.get_feature_infos()));
+        CHECK(pre->result.steps == qp->result.steps && pre->result.best_hyp == qp->result.best_hyp && pre->result.inliers == qp->result.inliers);
+        const Vector3d Ca = again.camera_position();
+        CHECK(Ca(0, 0) == Cq(0, 0) && Ca(1, 0) == Cq(1, 0) && Ca(2, 0) == Cq(2, 0) && again.focal_length() == query.focal_length());
+        bool threw = false;
+        try { pre->Process(again); } catch (const std::logic_error &) { threw = true; }
+        CHECK(threw);                                                                   // no model: Process(Query&) cannot match
+        // benchmark.hpp:17 with the reference's arguments; the golden pose is the planted one
+        const std::string out = dir + "/benchmark.txt";
+        std::vector<BenchmarkRow> rows = Benchmark(ql, pb, qp, dir + "/", out, nullptr);
+        CHECK(rows.size() == 1 && rows[0].index == 1 && rows[0].position_error < 3.0 && rows[0].rotation_error < 0.1 && std::fabs(rows[0].focal_length_error) < 60.0);
+        std::ifstream in(out);
+        std::string line;
+        CHECK((bool)std::getline(in, line) && std::count(line.begin(), line.end(), ',') == 4);
+    }
+}
+
+int main(int argc, char **argv)
+{
+    const std::string dir = argc > 1 ? argv[1] : "/tmp";
     try {
         test_p3p();
         test_p4pf();
@@ -411,6 +543,7 @@ int main()
         test_backmatching();
         test_benchmark();
         test_matching();
+        test_process_query_only(dir);
     } catch (const std::exception &e) {
         std::printf("EXCEPTION %s\n", e.what());
         return 2;

@@ -81,6 +81,34 @@ int main(int argc, char **argv)
     bool threw = false;
     try { LoadGoldenQuery(pb, 1, dir + "/"); } catch (const std::runtime_error &) { threw = true; }
     CHECK(threw);                                         // only one query line in the list
+    {   // query_loader.cpp:28-82, 153-177: the list file and the lazy .key read; copies share the descriptor bytes
+        std::ofstream l(dir + "/list.query.fused.txt");
+        l << "query/t.jpg 486 648 659.19732\nquery/missing.jpg 1024 768\nnot a query line\n";
+    }
+    QueryLoader ql(dir + "/", dir + "/");
+    CHECK(ql.GetQueryCount() == 2);
+    {
+        Query copy = ql.GetQuery(0, false);
+        CHECK(copy.image_name() == "t" && copy.image_width() == 486 && copy.image_height() == 648 && copy.focal_length() == 659.19732);
+        CHECK(copy.sift_keypoints().size() == 2 && copy.sift_descriptors().size() == 2);
+        Query second = copy;
+        ql.GetQuery(0, false);                                 // reloads the loader's own query; the copies keep their bytes
+        CHECK(second.sift_descriptors()[1][127] == (127 * 7 + 3) % 256 && second.sift_descriptors()[0][5] == 35);
+        CHECK(second.sift_keypoints()[0].x == 400.75f);
+        Query &none = ql.GetQuery(1, false);                    // no .key file: no features, unknown focal length
+        CHECK(none.focal_length() == 0.0 && none.sift_keypoints().empty() && none.image_width() == 1024);
+    }
+    {   // truncated and implausible files are refused without large allocations
+        { std::ofstream f(dir + "/trunc.key"); f << "2 128\n1 2 3 4\n 1 2 3\n"; }
+        CHECK(!sl.load_Lowe_features((dir + "/trunc.key").c_str()) && sl.get_nb_features() == 0);
+        { std::ofstream f(dir + "/huge.key"); f << "4000000000 128\n1 2 3 4\n"; }
+        CHECK(!sl.load_Lowe_features((dir + "/huge.key").c_str()));
+        { std::ofstream f(dir + "/huge.out"); f << "# Bundle file v0.3\n4000000000 4000000000\n"; }
+        parse_bundler bad;
+        CHECK(!bad.parse_data((dir + "/huge.out").c_str()) && bad.get_cameras().empty());
+        { std::ofstream f(dir + "/views.out"); f << "# Bundle file v0.3\n0 1\n1 2 3\n0 0 0\n4000000000 0 0 0 0\n"; }
+        CHECK(!bad.parse_data((dir + "/views.out").c_str()));
+    }
     std::printf(failures ? "%d check(s) failed\n" : "io ok\n", failures);
     return failures ? 1 : 0;
 }

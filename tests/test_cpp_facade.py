@@ -33,7 +33,7 @@ def test_io_readers_and_golden_pose_convention(tmp_path):
 
 
 @pytest.mark.gpu
-def test_facade_on_gpu():
-    r = subprocess.run([_exe()], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+def test_facade_on_gpu(tmp_path):
+    r = subprocess.run([_exe(), str(tmp_path)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
     assert r.returncode == 0, r.stdout.decode()
     assert b"facade ok" in r.stdout
