@@ -121,12 +121,20 @@ __global__ __launch_bounds__(64) void k_seg_solve_p3p(seg_launch L, const uint32
 
 // tail systems: [75][total hypotheses of the group], total = gridDim.y * S
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_seg_p4pf_elim(seg_launch L, const uint32_t *__restrict__ samples,
-                                                                                                 double *__restrict__ Arows, int *__restrict__ status, int batch)
+                                                                                                 double *__restrict__ Arows, int *__restrict__ status, int batch_min,
+                                                                                                 int batch_max, int wave_slots)
 {
     if (!seg_live(L, blockIdx.y)) return;
+    // systems per block: enough that the running queries' steps fill the chip's wave slots once, within
+    // what the grid has room for (batch_min) and the block's LDS holds (batch_max); a multiple of four
+    const int running = min(*L.n_active - L.a0, (int)gridDim.y);
+    const long long per_slot = ((long long)running * L.V + wave_slots - 1) / wave_slots;
+    const int batch = max(batch_min, min(batch_max, 4 * (int)((per_slot + 3) / 4)));
+    const uint32_t nbatch = ((uint32_t)L.V + batch - 1) / batch;
+    if (blockIdx.x >= nbatch) return;
     const size_t base = (size_t)blockIdx.y * L.S;
     p4pf_elim_block(seg_of(L, blockIdx.y).q, (uint32_t)L.V, samples + base * 4, nullptr, nullptr, Arows + base, (size_t)gridDim.y * L.S, status + base, batch,
-                    blockIdx.x, gridDim.x);
+                    blockIdx.x, nbatch);
 }
 
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_seg_p4pf_finish(seg_launch L, const uint32_t *__restrict__ samples,

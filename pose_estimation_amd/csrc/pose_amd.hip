@@ -1528,10 +1528,19 @@ static int batch_run_segmented(pose_amd_batch *b, int sample_mode, uint64_t seed
     // A short list leaves the chip mostly idle, so its wasted steps cost little and its rounds, each a chain
     // of about twenty dependent launches, cost everything: it starts with 256 steps (100 queries: 2.04 -> 1.75 ms
     // per pass; 800 queries: 4.9 -> 5.3 ms, so long lists keep 128).
-    uint32_t first_len = nlive < 300 ? 256u : 128u, growth = 5u;
+    // Each solver has its own schedule (its chain of launches runs on its own stream): [0] P3P, [1] P4Pf.
+    // POSE_AMD_SEG_ROUNDS="first,growth" sets both, "first,growth,first,growth" P3P then P4Pf.
+    // The P4Pf chain is the longer one (elimination, eigen step) and its queries need more steps, so it keeps few, long
+    // rounds; the P3P queries' chain has time to spare beside it and takes short rounds that double (measured on
+    // the 800-query list: 4.88 -> 4.56 ms per pass, 720 000 -> 645 000 steps computed for 368 000 needed).
+    const bool short_list = nlive < 300;
+    uint32_t first_len[2] = {short_list ? 256u : 64u, short_list ? 256u : 128u}, growth[2] = {short_list ? 5u : 2u, 5u};
     if (const char *e = getenv("POSE_AMD_SEG_ROUNDS")) {
-        unsigned a1 = 0, a2 = 0;
-        if (sscanf(e, "%u,%u", &a1, &a2) == 2 && a1 >= 16 && a2 >= 2) { first_len = std::min(a1, 16384u); growth = std::min(a2, 16u); }
+        unsigned a[4] = {0, 0, 0, 0};
+        const int got = sscanf(e, "%u,%u,%u,%u", &a[0], &a[1], &a[2], &a[3]);
+        if (got == 2) { a[2] = a[0]; a[3] = a[1]; }
+        if ((got == 2 || got == 4) && a[0] >= 16 && a[1] >= 2 && a[2] >= 16 && a[3] >= 2)
+            for (int k = 0; k < 2; ++k) { first_len[k] = std::min(a[2 * k], 16384u); growth[k] = std::min(a[2 * k + 1], 16u); }
     }
     // bytes of per-hypothesis arrays a pass may use: a round whose list of running queries may be
     // longer than that is issued as several passes (the later ones usually find the list ended)
@@ -1557,6 +1566,9 @@ static int batch_run_segmented(pose_amd_batch *b, int sample_mode, uint64_t seed
     // matrix-core scoring: most blocks that may share a batch of poses along the correspondences (1: whole-range blocks only)
     int seg_shares = 8;
     if (const char *e = getenv("POSE_AMD_SEG_SCORE_SHARES")) seg_shares = std::max(1, std::min(16, atoi(e)));
+    // (a grid of 16 000 blocks and more measured 5 % slower for the 800-query list: the idle blocks are not free)
+    long long elim_grid_cap = 4096;
+    if (const char *e = getenv("POSE_AMD_SEG_ELIM_GRID")) elim_grid_cap = std::max(1, atoi(e));
     int cov_blocks[2] = {1, 2};
     if (const char *e = getenv("POSE_AMD_SEG_COV_BLOCKS")) {
         int a1 = 0, a2 = 0;
@@ -1577,12 +1589,16 @@ static int batch_run_segmented(pose_amd_batch *b, int sample_mode, uint64_t seed
         HIPCHK(ctx, hipEventRecord(ctx->seg_ev[0], ctx->stream));                  // tables, lists, zeroed state
         HIPCHK(ctx, hipStreamWaitEvent(ctx->seg_stream, ctx->seg_ev[0], 0));
     }
-    uint32_t step0 = 0, next_len = early ? first_len : 16384u;
-    while (step0 < budget) {
-        const uint32_t valid = std::min(next_len, budget - step0);
-        const int S = (int)((valid + 63) / 64 * 64);
+    uint32_t step0_of[2] = {0, 0}, next_len[2] = {early ? first_len[0] : 16384u, early ? first_len[1] : 16384u};
+    // rounds are issued solver by solver in turn, so that both streams have work from the start
+    while ((nsolver[0] > 0 && step0_of[0] < budget) || (nsolver[1] > 0 && step0_of[1] < budget)) {
         for (int solver = 0; solver < 2; ++solver) {
-            if (nsolver[solver] == 0) continue;
+            if (nsolver[solver] == 0 || step0_of[solver] >= budget) continue;
+            const uint32_t step0 = step0_of[solver];
+            const uint32_t valid = std::min(next_len[solver], budget - step0);
+            const int S = (int)((valid + 63) / 64 * 64);
+            step0_of[solver] = step0 + valid;
+            next_len[solver] = std::min<uint32_t>(16384u, next_len[solver] * growth[solver]);
             const int maxsol = solver ? P4PF_MAXSOL : P3P_MAXSOL;
             pose_amd_ctx::seg_scratch &G = ctx->sgs[solver];
             hipStream_t stream = streams[solver];
@@ -1622,8 +1638,13 @@ static int batch_run_segmented(pose_amd_batch *b, int sample_mode, uint64_t seed
                     // batch size as in launch_p4pf: 32 systems per block unless that leaves wave slots of the chip empty
                     const int wslots = (ctx->cus ? ctx->cus : 256) * 8;
                     const int batch = std::max(4, std::min(4 * cdiv(cdiv((long long)na * valid, wslots), 4), ELIM_BATCH));
-                    hipLaunchKernelGGL(k_seg_p4pf_elim, dim3(cdiv(valid, batch), (unsigned)na), dim3(64), 0, stream, L, (const uint32_t *)samples,
-                                       (double *)G.arows.p, (int *)G.pstatus.p, batch);
+                    // ... for a list as long as the pass allows.  The kernel sizes the batch for the list's real length (a block
+                    // eliminates its systems four at a time, one pass after the other: short lists want short batches); the
+                    // grid has room for batches down to bmin systems, bounded so that long lists do not launch crowds of idle blocks
+                    int bmin = 4;
+                    while (bmin < batch && (long long)cdiv(valid, bmin) * (long long)na > elim_grid_cap) bmin += 4;
+                    hipLaunchKernelGGL(k_seg_p4pf_elim, dim3(cdiv(valid, bmin), (unsigned)na), dim3(64), 0, stream, L, (const uint32_t *)samples,
+                                       (double *)G.arows.p, (int *)G.pstatus.p, bmin, batch, wslots);
                     if ((rc = mark(2))) return rc;
                     hipLaunchKernelGGL(k_seg_p4pf_finish, dim3(cdiv(valid, 64), (unsigned)na), dim3(64), 0, stream, L, (const uint32_t *)samples,
                                        (const double *)G.arows.p, (const int *)G.pstatus.p, proj, pose, nsol, projf, prm->eps);
@@ -1642,7 +1663,7 @@ static int batch_run_segmented(pose_amd_batch *b, int sample_mode, uint64_t seed
                     const long long bx = cdiv((long long)valid * maxsol, big ? MS_POSES : SEG_MFMA_WAVES * 64);
                     // blocks that may share a batch of poses along the correspondences (the kernel decides how many do, from the
                     // number of running queries); bounded so that a long list's launch does not grow by blocks that only leave
-                    const unsigned shares = (unsigned)std::max<long long>(1, std::min<long long>(seg_shares, 8192 / std::max<long long>(1, bx * (long long)na)));
+                    const unsigned shares = (unsigned)std::max<long long>(1, std::min<long long>(seg_shares, 32768 / std::max<long long>(1, bx * (long long)na)));
                     hipLaunchKernelGGL(k_seg_compact_valid, dim3(cdiv((long long)valid * maxsol, MS_COMPACT_SLOTS), (unsigned)na), dim3(256), 0, stream, L, maxsol,
                                        (const int *)nsol, (int *)G.vlist.p, (unsigned int *)G.vcount.p, counts, shares > 1 ? 1 : 0);
                     const int target_blocks = 2 * (ctx->cus ? ctx->cus : 256);
@@ -1705,8 +1726,6 @@ static int batch_run_segmented(pose_amd_batch *b, int sample_mode, uint64_t seed
                 }
             }
         }
-        step0 += valid;
-        next_len = std::min<uint32_t>(16384u, next_len * growth);
     }
     if (two_streams) {
         HIPCHK(ctx, hipEventRecord(ctx->seg_ev[1], ctx->seg_stream));
