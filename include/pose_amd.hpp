@@ -333,8 +333,44 @@ public:
 
     // query_processor.cpp:36-44: the reference's refinement step is an empty function that returns
     // true (its Levenberg-Marquardt is a TODO there); Process calls it between ComputeMatrices and
-    // the final Project (basic.cpp:299, advanced.cpp:613), so it exists here with the same effect.
-    bool BundleAdjust(Query &, std::vector<SiftMatch> &, std::vector<SIFT_keypoint> &, std::vector<feature_3D_info> &) { return true; }
+    // the final Project (basic.cpp:299, advanced.cpp:613).  By default it does the same here.
+    // With `local_optimisation` set it does what the report's outlook names as the next step, a local
+    // optimisation on the fitted matches: `lo_steps` more RANSAC steps whose minimal samples are drawn
+    // from the fitted matches only, every pose scored against ALL matches with the processor's own
+    // criterion; the kept pose, fitted_matches and the fit points change only if a pose is strictly
+    // better.  The reference has nothing to compare this with (parity unpinned); it only acts
+    // inside Process, which knows the full match list.
+    bool local_optimisation = false;
+    uint32_t lo_steps = 64;
+    std::vector<uint32_t> lo_samples;       // the tuples of the last local optimisation (indices into good_matches)
+    bool lo_improved = false;
+    bool BundleAdjust(Query &query, std::vector<SiftMatch> &fitted, std::vector<SIFT_keypoint> &sift_keypoints, std::vector<feature_3D_info> &sifts)
+    {
+        lo_samples.clear();
+        lo_improved = false;
+        const int m = solver_focal_ == 0.0 ? 4 : 3;
+        if (!local_optimisation || !cur_matches_ || !result.found || fitted.size() < 8 || lo_steps == 0) return true;
+        // positions of the fitted matches in the full list (fitted keeps the list's order)
+        std::vector<uint32_t> pos;
+        {
+            size_t k = 0;
+            for (size_t i = 0; i < cur_matches_->size() && k < fitted.size(); ++i)
+                if ((*cur_matches_)[i].lindex == fitted[k].lindex && (*cur_matches_)[i].mindex == fitted[k].mindex) { pos.push_back((uint32_t)i); ++k; }
+            if (k != fitted.size()) return true;
+        }
+        // tuples among the fitted matches from the counter-based generator (a stream range of its own)
+        upload(query, fitted, sift_keypoints, sifts, false);
+        std::vector<uint32_t> t((size_t)lo_steps * 4);
+        dev_->check(pose_amd_sample(dev_->ctx(), POSE_AMD_SAMPLE_BASIC, seed, query_id, 0x40000000u, lo_steps, t.data()), "sample");
+        for (size_t i = 0; i < t.size(); ++i) t[i] = (i % 4) < (size_t)m ? pos[t[i]] : 0u;
+        lo_samples = t;
+        upload(query, *cur_matches_, sift_keypoints, sifts, false);
+        dev_->check(pose_amd_set_samples(dev_->ctx(), t.data(), lo_steps), "set_samples");
+        const uint32_t steps_before = result.steps;
+        lo_improved = decide(query, *cur_matches_, 0);
+        result.steps = steps_before;                  // the loop's own step count stays what the reference counts
+        return true;
+    }
 
     // Inliers of query.proj_matrix() among `matches` and the coverage quality (query_processor.cpp:88-177).
     std::vector<SiftMatch> TestHypothesis(Query &query, std::vector<SiftMatch> &matches, std::vector<SIFT_keypoint> &sift_keypoints,
@@ -392,6 +428,12 @@ protected:
         const size_t old = samples.size();
         samples.resize(old + (size_t)steps * 4);
         dev_->check(pose_amd_sample(dev_->ctx(), sample_mode, seed, query_id, hyp_begin, steps, samples.data() + old), "sample");
+        return decide(query, matches, early_exit);
+    }
+
+    // the loop over the tuples the context holds; a pose that beats the kept one replaces it
+    bool decide(Query &query, std::vector<SiftMatch> &matches, int early_exit)
+    {
         pose_amd_params prm;
         std::memset(&prm, 0, sizeof prm);
         prm.select_mode = select_mode; prm.eps = inlier_eps; prm.early_exit = early_exit;
@@ -435,12 +477,18 @@ public:
 
 protected:
     // what the reference does after its loop (basic.cpp:296-307): final matrices, reprojected fitted matches
-    void finish(Query &query)
+    void finish(Query &query, std::vector<SiftMatch> &matches, std::vector<feature_3D_info> &sifts)
     {
         query.ComputeMatrices(dev_);
+        cur_matches_ = &matches;
+        std::vector<SiftMatch> fitted = fitted_matches;          // BundleAdjust may replace fitted_matches
+        BundleAdjust(query, fitted, query.sift_keypoints(), sifts);
+        cur_matches_ = nullptr;
+        if (lo_improved) query.ComputeMatrices(dev_);
         query.set_fitpoints_2d(fit2d_);
         query.set_fitpoints_3d(fit3d_);
     }
+    std::vector<SiftMatch> *cur_matches_ = nullptr;          // the full match list while Process runs
     // basic.cpp:60-96 / advanced.cpp:242-285: two nearest model descriptors of every query descriptor,
     // Lowe's ratio test on the squared distances; with_camsets fills SiftMatch::camset from the view lists
     void match(Query &query, float ratio, bool with_camsets)
@@ -480,7 +528,7 @@ public:
         upload(query, good_matches, query.sift_keypoints(), sifts, false);
         run(query, good_matches, POSE_AMD_SAMPLE_BASIC, 0, max_ransac_steps, 1);
         samples.resize((size_t)result.steps * 4);
-        finish(query);
+        finish(query, good_matches, sifts);
         return true;
     }
 
@@ -580,7 +628,7 @@ public:
             // steps restart, the kept pose and its quality carry over (advanced.cpp:597-602)
             if (run(query, good_matches, POSE_AMD_SAMPLE_ADVANCED, max_ransac_steps, max_ransac_steps, 0)) best_leg = 1;
         }
-        finish(query);
+        finish(query, good_matches, sifts);
         return true;
     }
 };

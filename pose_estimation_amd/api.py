@@ -481,9 +481,51 @@ class QueryProcessor:
             return p2[0], p3
         return p2[0][matches], p3[matches]
 
+    # BundleAdjust with local_optimisation set: lo_steps more RANSAC steps whose minimal samples are
+    # drawn among the fitted matches, every pose scored against all matches
+    local_optimisation = False
+    lo_steps = 64
+
     def BundleAdjust(self, query, fitted_matches=None):
         """query_processor.cpp:36-44: an empty function that returns true in the reference (its
-        refinement is a TODO there); called between ComputeMatrices and the final Project."""
+        refinement is a TODO there); called between ComputeMatrices and the final Project.  The
+        same here unless `local_optimisation` is set: then the step the report's outlook names runs --
+        RANSAC on samples of the fitted matches only, scored on all matches with the processor's
+        criterion; pose, fitted_mask and fit points change only for a strictly better pose.  The
+        reference has nothing to compare this with (parity unpinned)."""
+        self.lo_samples, self.lo_improved = None, False
+        res = getattr(self, "result", None)
+        if not self.local_optimisation or fitted_matches is None or res is None or not res["found"] or self.lo_steps <= 0:
+            return True
+        pos = np.nonzero(np.asarray(fitted_matches, bool))[0]
+        if len(pos) < 8:
+            return True
+        focal = getattr(self, "_solver_focal", query.focal_length())
+        m = 4 if focal == 0.0 else 3
+        li = None if query.lindex is None else query.lindex[pos]
+        self.ctx.set_query(query.kx[pos], query.ky[pos], query.X[pos], query.Y[pos], query.Z[pos], query.image_width(), query.image_height(), focal, li)
+        t = self.ctx.sample(SAMPLE_BASIC, self.seed, getattr(self, "_query_id", 0), 0x40000000, self.lo_steps)
+        t = np.where(np.arange(4)[None, :] < m, pos[np.minimum(t, len(pos) - 1)], 0).astype(np.uint32)
+        self.lo_samples = t
+        self.ctx.set_query(query.kx, query.ky, query.X, query.Y, query.Z, query.image_width(), query.image_height(), focal, query.lindex)
+        self.ctx.set_samples(t)
+        r = self.ctx.ransac_run(self.select_mode, self.inlier_eps, False, self.inlier_divisor, self.inlier_absolute)
+        if not r["found"]:
+            return True
+        if self.select_mode == SELECT_COVERAGE:
+            better = np.float32(r["area_fit"]) / np.float32(r["area_all"]) > np.float32(res["area_fit"]) / np.float32(res["area_all"])
+        else:
+            better = r["inliers"] > res["inliers"]
+        if better:
+            r["steps"] = res["steps"]
+            self.result, self.lo_improved = r, True
+            if focal == 0.0:
+                query.set_focal_length(r["focal"])
+            query.set_camera_position(r["C"])
+            query.set_camera_rotation(r["Rc"])
+            mm, query.fitpoints_2d, query.fitpoints_3d = self.ctx.best_fit()
+            query.fitted_mask = mm.astype(bool)
+            query.ComputeMatrices(self.ctx)
         return True
 
     def TestHypothesis(self, query, match_eps=0.5):
@@ -515,6 +557,7 @@ class QueryProcessorBasic(QueryProcessor):
         self.steps = 0
 
     def Process(self, query, query_id=0):
+        self._solver_focal, self._query_id = query.focal_length(), query_id
         self._upload(query)
         # all tuples of the step budget are drawn up front (they are independent of the
         # outcome of earlier steps); ransac_run consumes them in order and stops early
@@ -553,6 +596,7 @@ class QueryProcessorAdvanced(QueryProcessorBasic):
         self.backmatch = backmatch
 
     def Process(self, query, query_id=0):
+        self._solver_focal, self._query_id = query.focal_length(), query_id
         self._upload(query)
         s1 = self.ctx.sample(self.sample_mode, self.seed, query_id, 0, self.max_ransac_steps)
         r = self.ctx.ransac_run(self.select_mode, self.inlier_eps, False, self.inlier_divisor, self.inlier_absolute)

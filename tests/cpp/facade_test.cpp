@@ -7,6 +7,7 @@
 #include <cstdlib>
 #include <iomanip>
 #include <random>
+#include <set>
 #include <string>
 
 #include "pose_amd.hpp"
@@ -531,6 +532,36 @@ static void test_process_query_only(const std::string &dir)
     }
 }
 
+// BundleAdjust with local_optimisation: the default leaves Process exactly as the reference's no-op
+// does; switched on, 64 more steps sample among the fitted matches only, and the kept pose can only
+// get better by the processor's own criterion.
+static void test_local_optimisation()
+{
+    for (int known = 0; known < 2; ++known) {
+        Scene a = make_scene(900, 300, known != 0, 90u + known), b = make_scene(900, 300, known != 0, 90u + known);
+        QueryProcessorBasic plain, lo;
+        plain.seed = lo.seed = 17;
+        lo.local_optimisation = true;
+        CHECK(plain.Process(a.query, a.matches, a.sifts) && lo.Process(b.query, b.matches, b.sifts));
+        CHECK(plain.lo_samples.empty() && !plain.lo_improved);
+        CHECK(lo.samples == plain.samples && lo.result.steps == plain.result.steps);          // the loop itself is untouched
+        CHECK(lo.lo_samples.size() == 4 * (size_t)lo.lo_steps);
+        // every tuple index names a match the loop's pose had fitted
+        std::set<unsigned> fitted;
+        for (const SiftMatch &m : plain.fitted_matches) fitted.insert(m.lindex);
+        bool inside = true;
+        for (size_t i = 0; i < lo.lo_samples.size(); ++i)
+            if ((i % 4) < (known ? 3u : 4u)) inside = inside && fitted.count(b.matches[lo.lo_samples[i]].lindex) == 1;
+        CHECK(inside);
+        const float q0 = (float)plain.result.area_fit / (float)plain.result.area_all, q1 = (float)lo.result.area_fit / (float)lo.result.area_all;
+        CHECK(q1 >= q0 && (lo.lo_improved == (q1 > q0)));
+        CHECK(lo.fitted_matches.size() == lo.result.inliers && b.query.fitpoints_2d().size() == lo.result.inliers);
+        if (!lo.lo_improved) CHECK(lo.result.best_hyp == plain.result.best_hyp && b.query.camera_position()(0, 0) == a.query.camera_position()(0, 0));
+        else CHECK(lo.result.inliers >= 12);
+        std::printf("local optimisation (%s): quality %.4f -> %.4f, inliers %u -> %u\n", known ? "P3P" : "P4Pf", q0, q1, plain.result.inliers, lo.result.inliers);
+    }
+}
+
 int main(int argc, char **argv)
 {
     const std::string dir = argc > 1 ? argv[1] : "/tmp";
@@ -544,6 +575,7 @@ int main(int argc, char **argv)
         test_benchmark();
         test_matching();
         test_process_query_only(dir);
+        test_local_optimisation();
     } catch (const std::exception &e) {
         std::printf("EXCEPTION %s\n", e.what());
         return 2;

@@ -74,7 +74,11 @@ def test_facades_have_the_reference_processor_interface():
         assert callable(getattr(api.QueryProcessor, name))
     for cls in (api.QueryProcessorBasic, api.QueryProcessorAdvanced):
         assert callable(cls.Process) and issubclass(cls, api.QueryProcessor)
-    assert api.QueryProcessor.BundleAdjust(None, None) is True      # query_processor.cpp:36-44 returns true and does nothing
+    # query_processor.cpp:36-44 returns true and does nothing; so does the default here (no device needed)
+    qp = api.QueryProcessor.__new__(api.QueryProcessor)
+    assert api.QueryProcessor.local_optimisation is False and qp.BundleAdjust(None, None) is True and qp.lo_samples is None
+    for name in ("Process(Query &query) override", "QueryProcessor(parse_bundler &parsebundler", "class QueryLoader"):
+        assert name in open(os.path.join(os.path.dirname(__file__), "..", "include", "pose_amd.hpp")).read()
     hpp = open(os.path.join(os.path.dirname(__file__), "..", "include", "pose_amd.hpp")).read()
     for name in ("bool Project(", "TestHypothesis(", "bool BundleAdjust(", "virtual bool Process("):
         assert name in hpp

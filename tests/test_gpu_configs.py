@@ -178,6 +178,34 @@ def test_process_fills_fitpoints_like_the_final_projection(ctx):
     assert np.array_equal(p2, e2[sub]) and np.array_equal(p3, e3[sub])
 
 
+def test_bundle_adjust_local_optimisation_is_off_by_default_and_never_worse(ctx):
+    """query_processor.cpp:36-44 is a no-op in the reference and by default here.  With
+    local_optimisation set, 64 more steps sample among the fitted matches only (scored on all
+    matches); the loop's own tuples and step count do not change and the kept pose is the loop's or a
+    strictly better one.  Parity unpinned: the reference holds nothing to compare the refinement with."""
+    for known, seed in ((False, 21), (True, 22)):
+        d = synth.make_query(1500, 0.3, seed, known_focal=known)
+        mk = lambda: Query(d["kx"], d["ky"], d["X"], d["Y"], d["Z"], d["width"], d["height"], d["focal"])   # noqa: E731
+        q0, q1 = mk(), mk()
+        plain, lo = QueryProcessorBasic(ctx, seed=5), QueryProcessorBasic(ctx, seed=5)
+        lo.local_optimisation = True
+        assert plain.Process(q0) and lo.Process(q1)
+        assert plain.lo_samples is None and np.array_equal(plain.samples, lo.samples) and plain.steps == lo.steps
+        m = 3 if known else 4
+        assert lo.lo_samples.shape == (64, 4) and q0.fitted_mask[lo.lo_samples[:, :m]].all()      # drawn among the loop's fitted matches
+        qa = np.float32(plain.result["area_fit"]) / np.float32(plain.result["area_all"])
+        qb = np.float32(lo.result["area_fit"]) / np.float32(lo.result["area_all"])
+        assert qb >= qa and lo.lo_improved == (qb > qa)
+        if lo.lo_improved:
+            # the refined pose comes from an all-inlier sample: closer to the planted camera than a pose that merely reached 12 inliers
+            assert q1.fitted_mask.sum() == lo.result["inliers"] >= 12 and q1.fitpoints_2d.shape == (lo.result["inliers"], 2)
+            assert np.linalg.norm(q1.camera_position() - d["C_true"]) < 3.0
+            o = O.ransac(*oracle_args(d), lo.lo_samples, select_coverage=True, early_exit=False, max_steps=64)
+            assert (lo.result["best_hyp"], lo.result["inliers"], lo.result["area_fit"]) == (o["best_step"], o["hyposet"], o["area_fit"])
+        else:
+            assert np.array_equal(q1.camera_position(), q0.camera_position())
+
+
 # ---- BASELINE configs[3]: advanced processor with its backmatching leg --------------------------------
 def advanced_case(n, n_in, seed, extra_frac):
     """A query whose first 100 co-occurrence-sampled steps cannot reach 12 inliers (only n_in < 12
