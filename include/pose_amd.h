@@ -56,8 +56,8 @@ int pose_amd_quartic_batch(pose_amd_ctx *ctx, int count, const double *factors, 
 int pose_amd_p4pf_batch(pose_amd_ctx *ctx, int count, const double *m2d, const double *M3D, int *nsol, double *f,
                         double *R, double *t);
 
-/* No counterpart in the reference.  For callers that cannot allocate device memory (code under
- * HIP graph capture, tight serving loops, harnesses that forbid hipMalloc): pose_amd_p4pf_batch
+/* No counterpart in the reference.  For callers that cannot allocate device memory (tight serving loops,
+ * harnesses that forbid hipMalloc): pose_amd_p4pf_batch
  * on DEVICE-resident inputs and outputs, same kernels and bit-identical results, whose
  * intermediate buffer (the reduced tail system of every problem, 604 bytes each) lives in a
  * static device array of POSE_AMD_NOALLOC_MAX_COUNT entries (9.9 MB per GPU, held until the

@@ -25,6 +25,8 @@ p = 16 * slot + lane % 16; one named register per (column, slot)):
            eliminated over both slots; 16 rows are active after it, slot 0 then has as many retired
            positions as slot 1 has active rows, the latter move into the former (through LDS, under
            EXEC masks) and the other 11 columns are eliminated in slot 0 alone.
+           The masked stores write EXEC inside inline assembly and restore it to all ones: the
+           generated function must be entered with all 64 lanes active (stated in its header).
   tail     the 5 rows left over hold a 5 x 15 system in columns 70..74 | 78..87; it is written
            out and solved per lane by the consumer (p4pf_reduce_tail), where it costs no
            cross-lane traffic.
@@ -512,6 +514,9 @@ def emit(sched):
     w("// * stride], written when wr is set.  Returns 0, or -1 when a pivot column had no usable entry.")
     w("// tab at the LDS copy of c_elim_tab, pbuf at ELIM_PBUF_VEC double2 of LDS scratch private to the")
     w("// lane's row of 16 lanes.")
+    w("// PRECONDITION: all 64 lanes of the wave are active at the call.  The masked LDS stores set EXEC")
+    w("// inside inline assembly and restore it to all ones, not to its value at entry, so a call from")
+    w("// divergent code would re-enable lanes; the callers branch on block-uniform values only.")
     w("__device__ __forceinline__ int p4pf_elim_wave(const double *cf, const uint4 *tab, double2 *pbuf, double *tail5x15, size_t stride, bool wr)")
     w("{")
     w("    const int lane = (int)(threadIdx.x & 63);")
