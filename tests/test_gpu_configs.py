@@ -415,6 +415,25 @@ def test_multi_query_launches_hand_crowded_queries_to_the_per_query_path(ctx, mo
         assert np.array_equal(a["C"], b["C"]) and np.array_equal(a["Rc"], b["Rc"]) and a["focal"] == b["focal"]
 
 
+@pytest.mark.parametrize("name,value", [("POSE_AMD_BATCH", "threads"), ("POSE_AMD_SEG_SCORE", "packed"), ("POSE_AMD_SEG_COVER", "bands"),
+                                        ("POSE_AMD_SEG_SCORE_SHARES", "1"), ("POSE_AMD_SEG_ROUNDS", "128,5"), ("POSE_AMD_SEG_ROUNDS", "32,2,512,3"),
+                                        ("POSE_AMD_SEG_ELIM_GRID", "1"), ("POSE_AMD_SEG_STREAMS", "1")])
+def test_environment_switches_select_paths_with_identical_results(ctx, monkeypatch, name, value):
+    """The documented switches (every one is read at the call, so they can be set at any time): the
+    per-query worker threads instead of the shared launches, the packed float32 screen for the
+    basic sampler's poses, the per-band coverage kernels, whole-range scoring blocks, other round
+    lengths, fixed elimination batches, one stream.  Every result equals the default path's, poses included."""
+    queries = mixed_queries()
+    kw = dict(seed=8, budget=1500, select_mode=SELECT_COVERAGE, early_exit=True)
+    want = ctx.ransac_batch(queries, SAMPLE_BASIC, **kw)
+    monkeypatch.setenv(name, value)
+    got = ctx.ransac_batch(queries, SAMPLE_BASIC, **kw)
+    for a, b in zip(want, got):
+        for k in RESULT_KEYS:
+            assert a[k] == b[k], (name, k)
+        assert np.array_equal(a["C"], b["C"]) and np.array_equal(a["Rc"], b["Rc"]) and a["focal"] == b["focal"]
+
+
 def test_resident_query_list_runs_any_number_of_times(ctx, monkeypatch):
     """pose_amd_batch_create / _run / _destroy: the list is uploaded once and then run with
     different samplers, selections, budgets and seeds; every run returns what pose_amd_ransac_batch
