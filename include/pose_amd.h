@@ -64,7 +64,9 @@ int pose_amd_p4pf_batch(pose_amd_ctx *ctx, int count, const double *m2d, const d
  * process ends) instead of a hipMalloc'ed one.  The call allocates nothing, is asynchronous on the
  * context's stream (pose_amd_synchronize waits for it) and returns POSE_AMD_EINVAL for
  * count > POSE_AMD_NOALLOC_MAX_COUNT.  All calls on one GPU share that array, whatever their
- * context: calls that overlap on one GPU race; issue them on one stream or serialise them. */
+ * context: the library orders them on the device (each call's stream waits for an event recorded
+ * behind the previous call's kernels on that GPU; the event exists from pose_amd_create on), so calls
+ * from several contexts or host threads run one after the other instead of overlapping. */
 #define POSE_AMD_NOALLOC_MAX_COUNT 16384
 int pose_amd_p4pf_batch_noalloc(pose_amd_ctx *ctx, int count, const double *m2d_dev, const double *M3D_dev, int *nsol_dev,
                                 double *f_dev, double *R_dev, double *t_dev);

@@ -35,6 +35,10 @@ void set_create_error(const std::string &msg) { std::lock_guard<std::mutex> g(g_
 constexpr int MAX_DEVICES = 64;
 std::mutex g_noalloc_lock;
 void *g_noalloc_scratch[MAX_DEVICES] = {nullptr};   // device address of `scratch` on each GPU
+// Recorded behind the kernels of the last allocation-free call on each GPU (created with the scratch
+// address, in pose_amd_create): the next call on that GPU, from whichever context, makes its stream
+// wait for it before it touches the array, so that calls which would overlap run one after the other.
+hipEvent_t g_noalloc_done[MAX_DEVICES] = {nullptr};
 
 struct dev_buf {
     void *p = nullptr;
@@ -252,6 +256,7 @@ int pose_amd_create(int device, pose_amd_ctx **out)
         if (!g_noalloc_scratch[device]) {
             void *ptr = nullptr;
             if ((e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch))) != hipSuccess) return bail("hipGetSymbolAddress(scratch)", e);
+            if ((e = hipEventCreateWithFlags(&g_noalloc_done[device], hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
             g_noalloc_scratch[device] = ptr;
         }
     }
@@ -412,6 +417,10 @@ int pose_amd_p4pf_batch_noalloc(pose_amd_ctx *ctx, int count, const double *m2d_
     void *sp = ctx->device < MAX_DEVICES ? g_noalloc_scratch[ctx->device] : nullptr;
     if (!sp) return fail(ctx, POSE_AMD_ESTATE, "p4pf_batch_noalloc: scratch address of this device was not resolved");
     HIPCHK(ctx, hipSetDevice(ctx->device));
+    // Enqueued under the lock, behind the previous call's event: every call on this GPU uses the same
+    // array, and two contexts (two streams) must not have their kernels in it at the same time.
+    std::lock_guard<std::mutex> order(g_noalloc_lock);
+    HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, g_noalloc_done[ctx->device], 0));     // a never-recorded event is complete
     double *arows = (double *)sp;                                    // [75][count], fully rewritten for every live problem
     int *pstatus = (int *)((char *)sp + NOALLOC_STATUS_OFFSET);      // [count], written for every problem by the elimination
     // unused solution slots read as zero, like pose_amd_p4pf_batch's outputs
@@ -429,6 +438,7 @@ int pose_amd_p4pf_batch_noalloc(pose_amd_ctx *ctx, int count, const double *m2d_
                        (const double *)arows, (const int *)pstatus, (double *)nullptr, (double *)nullptr, nsol_dev, f_dev, R_dev, t_dev,
                        (float *)nullptr, 0.0);
     HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipEventRecord(g_noalloc_done[ctx->device], ctx->stream));
     return POSE_AMD_OK;
 }
 

@@ -61,6 +61,33 @@ def test_noalloc_entry_point_equals_p4pf_batch(ctx):
     assert all(np.array_equal(g, e) for g, e in zip(got, exp))
 
 
+def test_noalloc_calls_from_two_contexts_are_ordered_on_the_device(ctx):
+    """Two contexts (two streams) of one GPU share the static array.  Their calls are issued back to
+    back without any synchronisation in between; the library makes each call's stream wait for the
+    previous call's kernels, so both results are those of pose_amd_p4pf_batch."""
+    from pose_estimation_amd import Context
+    m, M = synth.random_p4pf_problems(12000, 321)
+    halves = [(m[:8000], M[:8000]), (m[8000:], M[8000:])]
+    exp = [ctx.p4pf_batch(a, b) for a, b in halves]
+    with Context(0) as other:
+        for rep in range(3):
+            bufs = []
+            for c, (a, b) in zip((ctx, other), halves):
+                n = len(a)
+                d = [DeviceArray(np.ascontiguousarray(a, np.float64).reshape(n, 8)), DeviceArray(np.ascontiguousarray(b, np.float64).reshape(n, 12)),
+                     DeviceArray(np.full(n, -77, np.int32)), DeviceArray(np.full((n, 10), 3.25)), DeviceArray(np.full((n, 90), 3.25)), DeviceArray(np.full((n, 30), 3.25))]
+                bufs.append(d)
+            for c, d, (a, b) in zip((ctx, other), bufs, halves):           # both enqueued before either is waited for
+                c._chk(c._lib.pose_amd_p4pf_batch_noalloc(c._h, len(a), *[x.ptr for x in d]), "p4pf_batch_noalloc")
+            ctx.synchronize(); other.synchronize()
+            for d, e, (a, b) in zip(bufs, exp, halves):
+                n = len(a)
+                assert np.array_equal(d[2].get(), e[0]) and np.array_equal(d[3].get(), e[1])
+                assert np.array_equal(d[4].get().reshape(n, 10, 3, 3), e[2]) and np.array_equal(d[5].get().reshape(n, 10, 3), e[3])
+                for x in d:
+                    x.free()
+
+
 def test_noalloc_entry_point_rejects_sizes_beyond_its_scratch(ctx):
     z = DeviceArray(np.zeros(8))
     p = z.ptr
