@@ -1306,7 +1306,7 @@ __global__ __launch_bounds__(256) void k_coverage_direct(query_dev q, int nposes
 // below it).  In the rare case that the replay over the shortened range finds no end of the loop,
 // k_cov_final sets state word 7 and the caller repeats candidates + replay with limit_ok = 0.
 // ------------------------------------------------------------------------------------------
-constexpr int COVSEL_THREADS = 256;
+constexpr int COVSEL_THREADS = 1024;
 
 constexpr int COVSEL_K = 8;          // consecutive slots per thread and tile of the ordered scans
 

@@ -23,9 +23,15 @@ leave the elimination kernel with substantially fewer multiply-adds.
 Result (seed 1, profiles/r3_template_study.txt): with plain monomial multiples the action of zd needs
 multiples up to total degree 8; greedy pruning leaves 133 x 158 (1 388 non-zeros, 4 333 structural
 multiply-adds) where the reference's table has 78 x 88 (736 non-zeros, 3 861 in the same model).  The
-reference's table is not a set of plain multiples: 41 of its 78 rows lack entries their polynomial
-would have (monomials such as w^2 and w^2 zd have no column), which is how it stays that small.  A
-from-scratch template therefore offers no reduction; the kernel keeps the reference's table.
+reference's table is not a set of plain multiples: 39 of its 78 rows lack entries their polynomial
+would have (monomials such as w^2 and w^2 zd have no column): columns of excess monomials may be
+dropped as long as the square system stays regular, because the combination of rows that reduces a
+monomial exactly also solves the system without those columns (checked modulo p on the reference's
+table: the planted solution is an eigenvector of its action matrix).  With the reference's own basis
+(1, zd, zc, zb, w, zd^2, zd zc, zd zb, zd w, zc^2) multiples up to degree 7 suffice; pruning leaves
+107 rows, squared by dropping columns 107 x 117, 2 835 structural multiply-adds against 3 861: a
+quarter fewer in this model, at the price of a new pivoting structure and unknown conditioning, and
+no factor.  The kernel keeps the reference's table.
 
 Usage: tools/template_study.py [seed]
 """
