@@ -9,14 +9,18 @@ select the best pose.  Inputs are resident in HBM before the timed region.
 Other workloads (one JSON line each, same fields): --known-focal / --matches / --inlier-frac
 reshape the single-query run (configs[0] and configs[4] shapes); --workload dubrovnik runs the
 800-query batch of configs[2] (fixed budget, or --early-exit for the reference's loop) and
-configs[3] (--advanced).
+configs[3] (--advanced).  After the timed region of the default workload, short passes of those other
+configs run as well and are reported under config.other_workloads of the same line (--no-extras
+skips them), so that one run carries every BASELINE config.
 
 N > 1 GPUs: one rank per GPU.  Launched by torch.distributed.run the ranks find RANK / WORLD_SIZE
 in the environment; started plainly as `python bench.py --gpus N`, this script starts the N
 ranks itself as child processes (before anything touches the GPU) and relays rank 0's line.
 The single-query workload shards the hypothesis range (every rank evaluates its own 1 M
 hypotheses of the same query per step, weak scaling) and max-all-reduces the packed
-(inlier count, ~hypothesis id) keys over RCCL; the batch workload partitions the queries.
+(inlier count, ~hypothesis id) keys over RCCL; the batch workload gives every rank its own list of
+queries (--scaling weak, the default) or partitions one list over the ranks (--scaling strong), with
+no collective in the data path.
 
 Prints ONE JSON line on rank 0.
 """
