@@ -1574,7 +1574,8 @@ static int batch_run_segmented(pose_amd_batch *b, int sample_mode, uint64_t seed
             for (int i = 0; i < 4; ++i) pose_blocks[i] = std::min(v[i], 1024);
     }
     // matrix-core scoring: most blocks that may share a batch of poses along the correspondences (1: whole-range blocks only)
-    int seg_shares = 8;
+    int seg_shares = 8, seg_score_target = 0;
+    if (const char *e = getenv("POSE_AMD_SEG_SCORE_TARGET")) seg_score_target = std::max(0, atoi(e));
     if (const char *e = getenv("POSE_AMD_SEG_SCORE_SHARES")) seg_shares = std::max(1, std::min(16, atoi(e)));
     // (a grid of 16 000 blocks and more measured 5 % slower for the 800-query list: the idle blocks are not free)
     long long elim_grid_cap = 4096;
@@ -1676,7 +1677,7 @@ static int batch_run_segmented(pose_amd_batch *b, int sample_mode, uint64_t seed
                     const unsigned shares = (unsigned)std::max<long long>(1, std::min<long long>(seg_shares, 32768 / std::max<long long>(1, bx * (long long)na)));
                     hipLaunchKernelGGL(k_seg_compact_valid, dim3(cdiv((long long)valid * maxsol, MS_COMPACT_SLOTS), (unsigned)na), dim3(256), 0, stream, L, maxsol,
                                        (const int *)nsol, (int *)G.vlist.p, (unsigned int *)G.vcount.p, counts, shares > 1 ? 1 : 0);
-                    const int target_blocks = 2 * (ctx->cus ? ctx->cus : 256);
+                    const int target_blocks = seg_score_target > 0 ? seg_score_target : 2 * (ctx->cus ? ctx->cus : 256);
                     if (big)
                         hipLaunchKernelGGL((k_seg_score_mfma<MS_WAVES, MS_CHUNK_TILES>), dim3((unsigned)bx, (unsigned)na, shares), dim3(MS_THREADS), 0,
                                            stream, L, maxsol, (const double *)proj, (const int *)G.vlist.p, (const unsigned int *)G.vcount.p, prm->eps, counts, target_blocks);
