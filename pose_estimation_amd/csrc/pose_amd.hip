@@ -1677,7 +1677,7 @@ static int batch_run_segmented(pose_amd_batch *b, int sample_mode, uint64_t seed
                     const unsigned shares = (unsigned)std::max<long long>(1, std::min<long long>(seg_shares, 32768 / std::max<long long>(1, bx * (long long)na)));
                     hipLaunchKernelGGL(k_seg_compact_valid, dim3(cdiv((long long)valid * maxsol, MS_COMPACT_SLOTS), (unsigned)na), dim3(256), 0, stream, L, maxsol,
                                        (const int *)nsol, (int *)G.vlist.p, (unsigned int *)G.vcount.p, counts, shares > 1 ? 1 : 0);
-                    const int target_blocks = seg_score_target > 0 ? seg_score_target : 2 * (ctx->cus ? ctx->cus : 256);
+                    const int target_blocks = seg_score_target > 0 ? seg_score_target : 4 * (ctx->cus ? ctx->cus : 256);      // four 4-wave blocks fill a compute unit's wave slots for this kernel
                     if (big)
                         hipLaunchKernelGGL((k_seg_score_mfma<MS_WAVES, MS_CHUNK_TILES>), dim3((unsigned)bx, (unsigned)na, shares), dim3(MS_THREADS), 0,
                                            stream, L, maxsol, (const double *)proj, (const int *)G.vlist.p, (const unsigned int *)G.vcount.p, prm->eps, counts, target_blocks);
