@@ -449,6 +449,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 // P4Pf, stage C: one hypothesis per lane.  Action matrix -> accepted roots -> (f, R, t).
 // With proj != null the solutions go to the pose slots of the RANSAC pipeline, otherwise to
 // the flat arrays of the batch entry point.
+// WAVE_ISO: the real roots of the sextics are isolated for the wave as a whole (p4pf_isolate_wave)
+// instead of lane by lane in lock step; the results are the same bits.
+template <bool WAVE_ISO = true>
 __device__ __forceinline__ void p4pf_finish_block(const query_dev &q, uint32_t hyp_count, const uint32_t *__restrict__ samples, const double *__restrict__ m2d_in,
                               const double *__restrict__ M3D_in, const double *__restrict__ Arows, size_t tail_stride, const int *__restrict__ status,
                               double *__restrict__ proj, double *__restrict__ pose, int *__restrict__ nsol, double *__restrict__ fo,
@@ -459,14 +462,34 @@ __device__ __forceinline__ void p4pf_finish_block(const query_dev &q, uint32_t h
     // lanes busy.  Instead the roots of the whole wave are queued and recovered 64 at a time, one
     // per lane, by whichever lane gets them (it re-derives the normalised problem of the root's
     // hypothesis from the sample, which is cheap next to the rigid fit).
-    __shared__ p4pf_root s_root[128];
-    __shared__ unsigned short s_meta[128];               // source lane | root index << 8
+    // The queue shares its memory with the scratch of the root isolation, which is over by then.
+    struct recover_lds { p4pf_root root[128]; unsigned short meta[128]; };      // meta: source lane | root index << 8
+    __shared__ __align__(16) unsigned char s_raw[WAVE_ISO ? (sizeof(p4pf_iso_lds) > sizeof(recover_lds) ? sizeof(p4pf_iso_lds) : sizeof(recover_lds)) : sizeof(recover_lds)];
+    p4pf_root *s_root = reinterpret_cast<recover_lds *>(s_raw)->root;
+    unsigned short *s_meta = reinterpret_cast<recover_lds *>(s_raw)->meta;
     const int lane = threadIdx.x;
     const size_t h0 = (size_t)bx * blockDim.x, h = h0 + lane;
     const bool live = h < hyp_count;
     int n = live ? status[h] : -1;
     p4pf_root roots[10];
-    if (n == 0) {
+    if (WAVE_ISO) {
+        double a[50], p[11], q6[7] = {0, 0, 0, 0, 0, 0, 0}, qr6[7] = {0, 0, 0, 0, 0, 0, 0}, lam[12];
+        if (n == 0) {
+            p4pf_problem pb;
+            double m2d[8], M3D[12];
+            p4pf_fetch(q, samples, m2d_in, M3D_in, h, m2d, M3D);
+            p4pf_normalise(m2d, M3D, pb);
+            double tl[5][15];
+#pragma unroll
+            for (int i = 0; i < P4PF_TAIL; ++i) tl[i / 15][i % 15] = Arows[(size_t)i * tail_stride + h];
+            n = p4pf_reduce_tail(tl, a);
+            if (n == 0) n = p4pf_sextic(a, pb, p, q6, qr6);
+        }
+        const bool work = n == 0;
+        const int nl = p4pf_isolate_wave(*reinterpret_cast<p4pf_iso_lds *>(s_raw), work, q6, qr6, lam);
+        if (work) n = p4pf_polish(a, p, lam, nl, roots);
+        __builtin_amdgcn_wave_barrier();
+    } else if (n == 0) {
         p4pf_problem pb;
         double m2d[8], M3D[12];
         p4pf_fetch(q, samples, m2d_in, M3D_in, h, m2d, M3D);
@@ -530,12 +553,13 @@ __device__ __forceinline__ void p4pf_finish_block(const query_dev &q, uint32_t h
     }
 }
 
+template <bool WAVE_ISO = true>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_p4pf_finish(query_dev q, uint32_t hyp_count, const uint32_t *__restrict__ samples, const double *__restrict__ m2d_in,
                               const double *__restrict__ M3D_in, const double *__restrict__ Arows, const int *__restrict__ status,
                               double *__restrict__ proj, double *__restrict__ pose, int *__restrict__ nsol, double *__restrict__ fo,
                               double *__restrict__ Ro, double *__restrict__ to, float *__restrict__ projf, double eps)
 {
-    p4pf_finish_block(q, hyp_count, samples, m2d_in, M3D_in, Arows, (size_t)hyp_count, status, proj, pose, nsol, fo, Ro, to, projf, eps, blockIdx.x);
+    p4pf_finish_block<WAVE_ISO>(q, hyp_count, samples, m2d_in, M3D_in, Arows, (size_t)hyp_count, status, proj, pose, nsol, fo, Ro, to, projf, eps, blockIdx.x);
 }
 
 // Raw batched solver kernels for the parity entry points (inputs straight from the caller).

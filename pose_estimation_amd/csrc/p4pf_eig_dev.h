@@ -310,22 +310,20 @@ PA_HD int p4pf_reduce_tail(double (&t)[5][15], double (&a)[50])
     return bad ? -1 : 0;
 }
 
-// Action-matrix rows 5..9 (a[50], row-major 5x10) -> accepted roots, ascending zd.
-// Returns the count (0..6), or -1 when an eigenvector component is not finite.
-// STOP != 0 ends after a stage (1: characteristic polynomial, 2: root isolation); profiling only.
-template <int STOP = 0>
-PA_HD int p4pf_roots_sextic(const double (&a)[50], const p4pf_problem &pb, p4pf_root roots[10])
+// The eigen step in three stages, so that the kernel can run the middle one for a whole wave at once.
+//
+// Stage 1: action-matrix rows 5..9 (a[50], row-major 5x10) -> characteristic polynomial p[0..10]
+// and the sextic left after removing L^2 and ee(L) = |d|^2 L^2 - 2 a.d L + |a|^2, scaled to
+// largest coefficient 1: q ascending, qr reversed (roots 1/L).  Returns -1 for an unusable sextic.
+PA_HD int p4pf_sextic(const double (&a)[50], const p4pf_problem &pb, double (&p)[11], double (&q)[7], double (&qr)[7])
 {
-    double p[11];
     p4pf_charpoly(a, p);
-    if (STOP == 1) { roots[0].f = p[2] + p[5] + p[10]; roots[0].zb = p[3]; roots[0].zc = p[4]; roots[0].zd = p[6] + p[7] + p[8] + p[9]; return 1; }
-    // remove L^2 and ee(L) = |d|^2 L^2 - 2 a.d L + |a|^2
     const double ax = pb.m2D[0], ay = pb.m2D[1], dx = pb.m2D[6], dy = pb.m2D[7];
     const double e0 = ax * ax + ay * ay, e1 = -2.0 * (ax * dx + ay * dy), e2 = dx * dx + dy * dy;
     // Composite deflation: the quotient's high-order coefficients come from dividing top-down,
     // the low-order ones from dividing bottom-up (each direction is accurate at its own end,
     // whatever the magnitude spread of the coefficients); they are joined where they agree best.
-    double qt[7], qb[7], q[7];
+    double qt[7], qb[7];
     const double ie2 = p4pf_rcp(e2), ie0 = p4pf_rcp(e0);
     qt[6] = p[10] * ie2;
     qt[5] = (p[9] - e1 * qt[6]) * ie2;
@@ -349,25 +347,40 @@ PA_HD int p4pf_roots_sextic(const double (&a)[50], const p4pf_problem &pb, p4pf_
 #pragma unroll
     for (int i = 0; i < 7; ++i) sc = fmax(sc, fabs(q[i]));
     if (!(sc > 0.0) || !(sc < 1.79e308)) return -1;
-    double qr[7];
     const double isc = p4pf_rcp(sc);
 #pragma unroll
     for (int i = 0; i < 7; ++i) { q[i] *= isc; }
 #pragma unroll
     for (int i = 0; i < 7; ++i) qr[i] = q[6 - i];
-    // |L| <= 1 from q, |L| > 1 from the reversed polynomial (mu = 1/L in (-1, 1))
-    double lam[12];
-    double r1[6], r2[6];
-    const int n1 = poly_roots<6>::find(q, -1.0, 1.0, r1, P4PF_REFINE_TOL_TOP);
-    const int n2 = poly_roots<6>::find(qr, -1.0, 1.0, r2, P4PF_REFINE_TOL_TOP);
+    return 0;
+}
+
+// Stage 2 ends with this: roots of q in [-1, 1] and of the reversed sextic in (-1, 1) \ {0} -> eigenvalue
+// candidates lam[0 .. count), count <= 10.
+PA_HD int p4pf_merge_roots(const double (&r1)[6], int n1, const double (&r2)[6], int n2, double (&lam)[12])
+{
     int nl = 0;
 #pragma unroll
     for (int i = 0; i < 6; ++i) if (i < n1) { lam[nl < 12 ? nl : 0] = r1[i]; ++nl; }
 #pragma unroll
     for (int i = 0; i < 6; ++i)
         if (i < n2 && fabs(r2[i]) < 1.0 && r2[i] != 0.0) { lam[nl < 12 ? nl : 0] = 1.0 / r2[i]; ++nl; }
-    if (nl > 10) nl = 10;
-    if (STOP == 2) { roots[0].f = lam[0] + lam[1] + lam[2] + lam[3] + lam[4] + lam[5]; roots[0].zb = nl; roots[0].zc = 0; roots[0].zd = 0; return 1; }
+    return nl > 10 ? 10 : nl;
+}
+
+// Stage 2, one problem on its own: |L| <= 1 from q, |L| > 1 from the reversed polynomial (mu = 1/L in (-1, 1)).
+PA_HD int p4pf_isolate(const double (&q)[7], const double (&qr)[7], double (&lam)[12])
+{
+    double r1[6], r2[6];
+    const int n1 = poly_roots<6>::find(q, -1.0, 1.0, r1, P4PF_REFINE_TOL_TOP);
+    const int n2 = poly_roots<6>::find(qr, -1.0, 1.0, r2, P4PF_REFINE_TOL_TOP);
+    return p4pf_merge_roots(r1, n1, r2, n2, lam);
+}
+
+// Stage 3: Newton polish of every candidate on det P(L), eigenvector, acceptance test.
+// -> accepted roots, ascending zd; the count (0..10), or -1 when an eigenvector component is not finite.
+PA_HD int p4pf_polish(const double (&a)[50], const double (&p)[11], const double (&lam)[12], int nl, p4pf_root roots[10])
+{
     // derivative of the characteristic polynomial for the Newton polish
     double dp[10];
 #pragma unroll
@@ -409,6 +422,162 @@ PA_HD int p4pf_roots_sextic(const double (&a)[50], const p4pf_problem &pb, p4pf_
     }
     return nan ? -1 : n;
 }
+
+// Action-matrix rows 5..9 (a[50], row-major 5x10) -> accepted roots, ascending zd.
+// Returns the count (0..6), or -1 when an eigenvector component is not finite.
+// STOP != 0 ends after a stage (1: characteristic polynomial, 2: root isolation); profiling only.
+template <int STOP = 0>
+PA_HD int p4pf_roots_sextic(const double (&a)[50], const p4pf_problem &pb, p4pf_root roots[10])
+{
+    double p[11], q[7], qr[7], lam[12];
+    const int bad = p4pf_sextic(a, pb, p, q, qr);
+    if (STOP == 1) { roots[0].f = p[2] + p[5] + p[10]; roots[0].zb = p[3]; roots[0].zc = p[4]; roots[0].zd = p[6] + p[7] + p[8] + p[9]; return 1; }
+    if (bad) return -1;
+    const int nl = p4pf_isolate(q, qr, lam);
+    if (STOP == 2) { roots[0].f = lam[0] + lam[1] + lam[2] + lam[3] + lam[4] + lam[5]; roots[0].zb = nl; roots[0].zc = 0; roots[0].zd = 0; return 1; }
+    return p4pf_polish(a, p, lam, nl, roots);
+}
+
+#if defined(__HIPCC__)
+// ---- stage 2 for the 64 problems of a wave at once -------------------------------------------------
+// p4pf_isolate walks over every bracket of the derivative chain in lock step: 36 places where a
+// lane may have a root to refine, of which a lane uses 12 on average, and each costs the wave
+// the iterations of its slowest lane.  Here the brackets that do hold a root are queued in LDS,
+// level by level of the chain and for both sextics together, and refined 64 at a time, one per
+// lane, by whichever lane gets them.  Every bracket sees exactly the arithmetic of
+// poly_roots<N>::find (the same coefficients, ends and refinement), so the roots are the same bits.
+struct p4pf_iso_lds {
+    double coef[2][7][64];          // [sextic][coefficient][lane]: the current level's polynomials
+    double res[12][64];             // [bracket][lane]: refined roots
+    double ab[256][2];              // queue: bracket ends
+    unsigned short meta[256];       // queue: lane | bracket << 6
+};
+
+// One level: roots in [-1, 1] of the derivative of order 6 - N of q (s = 0) and qr (s = 1), given
+// those of the derivative of order 7 - N in crit / ncrit, which the new roots replace.
+// Every lane of the wave must call this; `work` says whether the lane has a problem.
+template <int N>
+__device__ __forceinline__ void p4pf_iso_level(p4pf_iso_lds &S, bool work, const double (&q)[7], const double (&qr)[7], double (&crit)[2][6],
+                                               int (&ncrit)[2], double tol)
+{
+    const int lane = threadIdx.x & 63;
+    // bracket k of sextic s is step s * N + k; its kind: 0 no root, 1 refined, 2 root at the upper end (= 1), 3 root at the lower end (= -1)
+    unsigned kinds = 0;
+    int next = 0;                  // steps below this one are done
+    while (next < 2 * N) {         // one turn unless the queue overflows (then the steps left over run in another)
+        const int first = next;
+        int qn = 0;
+        bool full = false;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            double c[N + 1];
+            {
+                double d[7];
+#pragma unroll
+                for (int i = 0; i < 7; ++i) d[i] = s ? qr[i] : q[i];
+#pragma unroll
+                for (int deg = 6; deg > N; --deg)
+#pragma unroll
+                    for (int i = 0; i < deg; ++i) d[i] = (i + 1) * d[i + 1];
+#pragma unroll
+                for (int i = 0; i <= N; ++i) c[i] = d[i];
+            }
+            if (first == 0) {
+#pragma unroll
+                for (int i = 0; i <= N; ++i) S.coef[s][i][lane] = c[i];
+            }
+            double a = -1.0, fa = poly_eval<N>(c, -1.0);
+#pragma unroll
+            for (int k = 0; k < N; ++k) {
+                const int st = s * N + k;
+                const double b = k < ncrit[s] ? crit[s][k < N - 1 ? k : 0] : 1.0;
+                const double fb = poly_eval<N>(c, b);
+                unsigned kind = 0;
+                if (b > a && ((fa < 0.0 && fb > 0.0) || (fa > 0.0 && fb < 0.0))) kind = 1;
+                else if (fb == 0.0 && (k >= ncrit[s]) && b > a) kind = 2;
+                else if (fa == 0.0 && k == 0) kind = 3;
+                if (!work) kind = 0;
+                if (st >= first && !full) {                 // wave-uniform
+                    const unsigned long long m = __ballot(kind == 1);
+                    const int add = __popcll(m);
+                    if (qn + add > 256) full = true;
+                    else {
+                        if (kind == 1) {
+                            const int pos = qn + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+                            S.ab[pos][0] = a; S.ab[pos][1] = b;
+                            S.meta[pos] = (unsigned short)(lane | (st << 6));
+                        }
+                        kinds |= kind << (2 * st);
+                        qn += add;
+                        next = st + 1;
+                    }
+                }
+                a = b; fa = fb;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        for (int r0 = 0; r0 < qn; r0 += 64) {
+            const int e = r0 + lane;
+            if (e < qn) {
+                const int src = S.meta[e] & 63, st = S.meta[e] >> 6, s = st >= N ? 1 : 0;
+                double c[N + 1];
+#pragma unroll
+                for (int i = 0; i <= N; ++i) c[i] = S.coef[s][i][src];
+                const double a = S.ab[e][0], b = S.ab[e][1];
+                S.res[st][src] = poly_refine<N>(c, a, b, poly_eval<N>(c, a), poly_eval<N>(c, b), tol);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        // the roots of this turn's steps come back before another turn may reuse the queue (results lie apart from it, so: at the end)
+    }
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        double out[6];
+        int n = 0;
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+            const unsigned kind = (kinds >> (2 * (s * N + k))) & 3u;
+            if (kind) {
+                const double root = kind == 1 ? S.res[s * N + k][lane] : kind == 2 ? 1.0 : -1.0;
+#pragma unroll
+                for (int j = 0; j < N; ++j) if (j == n) out[j] = root;
+                ++n;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < N; ++j) crit[s][j] = out[j];
+        ncrit[s] = n;
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
+// Stage 2 for a wave: every lane calls it, lanes with `work` get their candidates in lam / the count returned.
+__device__ __forceinline__ int p4pf_isolate_wave(p4pf_iso_lds &S, bool work, const double (&q)[7], const double (&qr)[7], double (&lam)[12])
+{
+    double crit[2][6];
+    int ncrit[2] = {0, 0};
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        // fourth derivative: a quadratic, solved in closed form
+        double d[7];
+#pragma unroll
+        for (int i = 0; i < 7; ++i) d[i] = s ? qr[i] : q[i];
+#pragma unroll
+        for (int deg = 6; deg > 2; --deg)
+#pragma unroll
+            for (int i = 0; i < deg; ++i) d[i] = (i + 1) * d[i + 1];
+        const double c2[3] = {d[0], d[1], d[2]};
+        double r[2];
+        ncrit[s] = work ? poly_roots<2>::find(c2, -1.0, 1.0, r) : 0;
+        crit[s][0] = r[0]; crit[s][1] = r[1];
+    }
+    p4pf_iso_level<3>(S, work, q, qr, crit, ncrit, P4PF_REFINE_TOL);
+    p4pf_iso_level<4>(S, work, q, qr, crit, ncrit, P4PF_REFINE_TOL);
+    p4pf_iso_level<5>(S, work, q, qr, crit, ncrit, P4PF_REFINE_TOL);
+    p4pf_iso_level<6>(S, work, q, qr, crit, ncrit, P4PF_REFINE_TOL_TOP);
+    return p4pf_merge_roots(crit[0], ncrit[0], crit[1], ncrit[1], lam);
+}
+#endif
 
 #undef PA_HD
 } // namespace pose_amd

@@ -222,8 +222,14 @@ static int launch_p4pf(pose_amd_ctx *ctx, const lane_io &io, uint32_t count, con
                        (double *)io.arows->p, (int *)io.pstatus->p, batch);
     HIPCHK(ctx, hipGetLastError());
     if (ctx->timing) HIPCHK(ctx, hipEventRecord(io.ev[4], io.stream));     // end of the elimination kernel, for the per-kernel timing
-    hipLaunchKernelGGL(k_p4pf_finish, dim3(cdiv(count, 64)), dim3(64), 0, io.stream, q, count, samples, m2d, M3D,
-                       (const double *)io.arows->p, (const int *)io.pstatus->p, proj, pose, nsol, fo, Ro, to, projf, eps);
+    // POSE_AMD_FINISH_ISO=lane: every lane isolates its own roots (the same results; kept for A/B measurements)
+    const char *iso = getenv("POSE_AMD_FINISH_ISO");
+    if (iso && !strcmp(iso, "lane"))
+        hipLaunchKernelGGL(k_p4pf_finish<false>, dim3(cdiv(count, 64)), dim3(64), 0, io.stream, q, count, samples, m2d, M3D,
+                           (const double *)io.arows->p, (const int *)io.pstatus->p, proj, pose, nsol, fo, Ro, to, projf, eps);
+    else
+        hipLaunchKernelGGL(k_p4pf_finish<true>, dim3(cdiv(count, 64)), dim3(64), 0, io.stream, q, count, samples, m2d, M3D,
+                           (const double *)io.arows->p, (const int *)io.pstatus->p, proj, pose, nsol, fo, Ro, to, projf, eps);
     HIPCHK(ctx, hipGetLastError());
     return POSE_AMD_OK;
 }
@@ -434,7 +440,7 @@ int pose_amd_p4pf_batch_noalloc(pose_amd_ctx *ctx, int count, const double *m2d_
     hipLaunchKernelGGL(k_p4pf_elim, dim3(cdiv(count, batch)), dim3(64), 0, ctx->stream, q, (uint32_t)count, (const uint32_t *)nullptr, m2d_dev, M3D_dev,
                        arows, pstatus, batch);
     HIPCHK(ctx, hipGetLastError());
-    hipLaunchKernelGGL(k_p4pf_finish, dim3(cdiv(count, 64)), dim3(64), 0, ctx->stream, q, (uint32_t)count, (const uint32_t *)nullptr, m2d_dev, M3D_dev,
+    hipLaunchKernelGGL(k_p4pf_finish<true>, dim3(cdiv(count, 64)), dim3(64), 0, ctx->stream, q, (uint32_t)count, (const uint32_t *)nullptr, m2d_dev, M3D_dev,
                        (const double *)arows, (const int *)pstatus, (double *)nullptr, (double *)nullptr, nsol_dev, f_dev, R_dev, t_dev,
                        (float *)nullptr, 0.0);
     HIPCHK(ctx, hipGetLastError());

@@ -165,6 +165,24 @@ def test_p4pf_batch_ragged_counts(ctx, count):
         assert np.array_equal(t[i, :k], t_all[i, :k])
 
 
+@pytest.mark.gpu
+def test_p4pf_root_isolation_of_a_wave_equals_lane_by_lane(ctx, monkeypatch):
+    """The real roots of the sextics are isolated for the 64 problems of a wave together (brackets
+    that hold a root are queued and refined one per lane); POSE_AMD_FINISH_ISO=lane keeps the
+    version in which every lane walks over its own brackets.  The arithmetic per bracket is the
+    same, so every output is the same bits: contaminated samples, degenerate ones and a last wave
+    that is not full included."""
+    m, M = synth.random_p4pf_problems(20011, 23)
+    M[5] = M[5, :1]                      # four times the same 3-D point
+    m[9] = m[9, :1]
+    wave = ctx.p4pf_batch(m, M)
+    monkeypatch.setenv("POSE_AMD_FINISH_ISO", "lane")
+    lane = ctx.p4pf_batch(m, M)
+    assert (wave[0] > 0).sum() > 15000 and (wave[0] >= 4).sum() > 500
+    for a, b in zip(wave, lane):
+        assert np.array_equal(a.view(np.int64) if a.dtype == np.float64 else a, b.view(np.int64) if b.dtype == np.float64 else b)
+
+
 def test_p4pf_lapack_fixture(ctx):
     """Committed problems whose roots (f, zb, zc, zd) come from LAPACK's eigen-solver (tools/gen_golden.py):
     the focal lengths against that fixture, and f, R, t against the long-double oracle, both at the
