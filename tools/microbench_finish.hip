@@ -1,6 +1,6 @@
 // Stage timing of the P4Pf finish kernel on random minimal problems:
-//   stage 1 characteristic polynomial, 2 + deflation and real-root isolation,
-//   3 + Newton polish and eigenvector (complete eigen step), 4 + pose recovery (complete kernel body).
+//   stage 1 tail solve, characteristic polynomial and deflation, 2 + real-root isolation (for the wave as a
+//   whole and lane by lane), 3 + Newton polish and eigenvector (complete eigen step), 4 + pose recovery.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -10,45 +10,51 @@
 using namespace pose_amd;
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
 
-template <int STAGE>
-__global__ void k_stage(uint32_t count, const double *__restrict__ m2d_in, const double *__restrict__ M3D_in,
+template <int STAGE, bool WAVE>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_stage(uint32_t count, const double *__restrict__ m2d_in, const double *__restrict__ M3D_in,
                         const double *__restrict__ Arows, const int *__restrict__ status, double *__restrict__ out)
 {
+    __shared__ p4pf_iso_lds S;
     const size_t h = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (h >= count) return;
-    if (status[h] != 0) { out[h] = 0; return; }
-    double m2d[8], M3D[12];
-    for (int i = 0; i < 8; ++i) m2d[i] = m2d_in[8 * h + i];
-    for (int i = 0; i < 12; ++i) M3D[i] = M3D_in[12 * h + i];
+    bool work = h < count && status[h] == 0;
+    double a[50], p[11], q6[7] = {0, 0, 0, 0, 0, 0, 0}, qr6[7] = {0, 0, 0, 0, 0, 0, 0}, lam[12];
     p4pf_problem pb;
-    p4pf_normalise(m2d, M3D, pb);
-    double tl[5][15], a[50];
-    for (int i = 0; i < P4PF_TAIL; ++i) tl[i / 15][i % 15] = Arows[(size_t)i * count + h];
-    if (p4pf_reduce_tail(tl, a) != 0) { out[h] = -1; return; }
-    p4pf_root roots[10];
     double acc = 0;
-    if (STAGE <= 2) {
-        const int n = p4pf_roots_sextic<STAGE>(a, pb, roots);
-        acc = n + roots[0].f + roots[0].zb + roots[0].zc + roots[0].zd;
-    } else {
-        const int n = p4pf_roots_sextic<0>(a, pb, roots);
+    if (work) {
+        double m2d[8], M3D[12];
+        for (int i = 0; i < 8; ++i) m2d[i] = m2d_in[8 * h + i];
+        for (int i = 0; i < 12; ++i) M3D[i] = M3D_in[12 * h + i];
+        p4pf_normalise(m2d, M3D, pb);
+        double tl[5][15];
+        for (int i = 0; i < P4PF_TAIL; ++i) tl[i / 15][i % 15] = Arows[(size_t)i * count + h];
+        if (p4pf_reduce_tail(tl, a) != 0) { work = false; acc = -1; }
+    }
+    if (work && p4pf_sextic(a, pb, p, q6, qr6) != 0) { work = false; acc = -1; }
+    if (STAGE == 1) { if (h < count) out[h] = work ? q6[0] + q6[1] + q6[2] + q6[3] + q6[4] + q6[5] + q6[6] + p[3] : acc; return; }
+    int nl = 0;
+    if (WAVE) nl = p4pf_isolate_wave(S, work, q6, qr6, lam);
+    else if (work) nl = p4pf_isolate(q6, qr6, lam);
+    if (STAGE == 2) { if (h < count) { for (int i = 0; i < 10; ++i) if (i < nl) acc += lam[i]; out[h] = acc + nl; } return; }
+    if (work) {
+        p4pf_root roots[10];
+        const int n = p4pf_polish(a, p, lam, nl, roots);
         acc = n;
         for (int s = 0; s < n; ++s) {
             if (STAGE == 3) acc += roots[s].f + roots[s].zd;
             else { double f, R[9], t[3]; p4pf_pose_from_root(pb, roots[s], f, R, t); acc += f + R[0] + R[4] + R[8] + t[0] + t[1] + t[2]; }
         }
     }
-    out[h] = acc;
+    if (h < count) out[h] = acc;
 }
 
-template <int STAGE>
+template <int STAGE, bool WAVE>
 float run(uint32_t n, const double *m, const double *M, const double *A, const int *st, double *out)
 {
     hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
-    k_stage<STAGE><<<(n + 63) / 64, 64>>>(n, m, M, A, st, out);
+    k_stage<STAGE, WAVE><<<(n + 63) / 64, 64>>>(n, m, M, A, st, out);
     CHECK(hipDeviceSynchronize());
     CHECK(hipEventRecord(e0));
-    k_stage<STAGE><<<(n + 63) / 64, 64>>>(n, m, M, A, st, out);
+    k_stage<STAGE, WAVE><<<(n + 63) / 64, 64>>>(n, m, M, A, st, out);
     CHECK(hipEventRecord(e1));
     CHECK(hipDeviceSynchronize());
     float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
@@ -85,9 +91,9 @@ int main(int argc, char **argv)
     }
     float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
     printf("n = %u\nelimination            %.3f ms\n", n, ms);
-    printf("stage 1 charpoly       %.3f ms\n", run<1>(n, dm, dM, dA, dst, dout));
-    printf("stage 2 + isolation    %.3f ms\n", run<2>(n, dm, dM, dA, dst, dout));
-    printf("stage 3 + polish       %.3f ms\n", run<3>(n, dm, dM, dA, dst, dout));
-    printf("stage 4 + pose         %.3f ms\n", run<4>(n, dm, dM, dA, dst, dout));
+    printf("stage 1 tail + sextic  %.3f ms\n", run<1, true>(n, dm, dM, dA, dst, dout));
+    printf("stage 2 + isolation    %.3f ms by wave, %.3f ms lane by lane\n", run<2, true>(n, dm, dM, dA, dst, dout), run<2, false>(n, dm, dM, dA, dst, dout));
+    printf("stage 3 + polish       %.3f ms by wave, %.3f ms lane by lane\n", run<3, true>(n, dm, dM, dA, dst, dout), run<3, false>(n, dm, dM, dA, dst, dout));
+    printf("stage 4 + pose         %.3f ms (recovery in lock step here; the kernel queues it)\n", run<4, true>(n, dm, dM, dA, dst, dout));
     return 0;
 }
