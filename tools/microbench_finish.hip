@@ -34,7 +34,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     int nl = 0;
     if (WAVE) nl = p4pf_isolate_wave(S, work, q6, qr6, lam);
     else if (work) nl = p4pf_isolate(q6, qr6, lam);
-    if (STAGE == 2) { if (h < count) { for (int i = 0; i < 10; ++i) if (i < nl) acc += lam[i]; out[h] = acc + nl; } return; }
+    if (STAGE == 2) { if (h < count) { for (int i = 0; i < 10; ++i) if (i < nl) acc += lam[i] * 1e-9; out[h] = acc + nl; } return; }
     if (work) {
         p4pf_root roots[10];
         const int n = p4pf_polish(a, p, lam, nl, roots);
@@ -95,5 +95,26 @@ int main(int argc, char **argv)
     printf("stage 2 + isolation    %.3f ms by wave, %.3f ms lane by lane\n", run<2, true>(n, dm, dM, dA, dst, dout), run<2, false>(n, dm, dM, dA, dst, dout));
     printf("stage 3 + polish       %.3f ms by wave, %.3f ms lane by lane\n", run<3, true>(n, dm, dM, dA, dst, dout), run<3, false>(n, dm, dM, dA, dst, dout));
     printf("stage 4 + pose         %.3f ms (recovery in lock step here; the kernel queues it)\n", run<4, true>(n, dm, dM, dA, dst, dout));
+    // candidates per problem after the isolation: what the polish loop, which runs in lock step, has to deal with
+    run<2, true>(n, dm, dM, dA, dst, dout);
+    std::vector<double> o(n);
+    CHECK(hipMemcpy(o.data(), dout, (size_t)n * 8, hipMemcpyDeviceToHost));
+    double sum = 0, summax = 0, over2 = 0, over3 = 0, own2 = 0;
+    long hist[12] = {0};
+    for (uint32_t w = 0; w + 64 <= n; w += 64) {
+        int mx = 0;
+        for (int l = 0; l < 64; ++l) {
+            const int nl = o[w + l] < 0 ? 0 : (int)(o[w + l] + 0.5);
+            hist[nl < 11 ? nl : 11]++;
+            sum += nl; mx = nl > mx ? nl : mx; over2 += nl > 2 ? nl - 2 : 0; over3 += nl > 3 ? nl - 3 : 0; own2 += nl > 2;
+        }
+        summax += mx;
+    }
+    const double nw = n / 64;
+    printf("candidates per lane %.2f, largest of a wave %.2f; per wave: beyond the second %.1f (from %.1f lanes), beyond the third %.1f\n", sum / n, summax / nw, over2 / nw,
+           own2 / nw, over3 / nw);
+    printf("histogram:");
+    for (int i = 0; i < 12; ++i) printf(" %ld", hist[i]);
+    printf("\n");
     return 0;
 }
