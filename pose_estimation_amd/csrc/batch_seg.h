@@ -148,8 +148,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                       proj + sbase * 12, pose + sbase * 13, nsol + base, nullptr, nullptr, nullptr, projf ? projf + sbase * 32 : nullptr, eps, blockIdx.x);
 }
 
-// packed-float32 screen + float64 decision, spb <= SCORE_SPB slots of one query per block
-__global__ __launch_bounds__(SCORE_THREADS) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_seg_score_screen(seg_launch L, int maxsol, const double *__restrict__ proj,
+#ifndef SEG_SCREEN_WAVES
+#define SEG_SCREEN_WAVES 5      // waves per SIMD: 96 registers instead of 80 take most spills out of the pose loop (5 % faster than 6 on the advanced batch, 4 no better)
+#endif
+// packed-float32 screen (certifying both sides: these are the co-occurrence sampler's poses) + float64 decision,
+// spb <= SCORE_SPB slots of one query per block
+__global__ __launch_bounds__(SCORE_THREADS) __attribute__((amdgpu_waves_per_eu(SEG_SCREEN_WAVES, SEG_SCREEN_WAVES))) void k_seg_score_screen(seg_launch L, int maxsol, const double *__restrict__ proj,
                                                                                                               const float *__restrict__ projf,
                                                                                                               const int *__restrict__ nsol, double eps,
                                                                                                               int *__restrict__ counts, int spb)
@@ -159,7 +163,7 @@ __global__ __launch_bounds__(SCORE_THREADS) __attribute__((amdgpu_waves_per_eu(6
     __shared__ int s_wave_n[SCORE_THREADS / 64];
     if (!seg_live(L, blockIdx.y)) return;
     const size_t base = (size_t)blockIdx.y * L.S, sbase = base * maxsol;
-    score_screen_block<false>(seg_of(L, blockIdx.y).q, L.V * maxsol, proj + sbase * 12, projf ? projf + sbase * 32 : nullptr, nsol + base, maxsol, eps, counts + sbase,
+    score_screen_block<false, true>(seg_of(L, blockIdx.y).q, L.V * maxsol, proj + sbase * 12, projf ? projf + sbase * 32 : nullptr, nsol + base, maxsol, eps, counts + sbase,
                               nullptr, 0, spb, blockIdx.x, s_cnt, s_list, s_wave_n);
 }
 

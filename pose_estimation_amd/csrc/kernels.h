@@ -749,8 +749,17 @@ __global__ __launch_bounds__(SCORE_THREADS) void k_score(query_dev q, int nslots
 // D > |te| is implied by D32 > k1 T + c with T = eps |pz32|, k1 = 1 + 2 eps32,
 // c = 1.0001 eps 4.01 eps32 Sz + 1.4143 E, and (k1 T + c)^2 <= T^2 (k1^2 + kappa) +
 // c^2 (1 + k1^2 / kappa), kappa = 2^-6.  The factors (1 + 2^-20) below absorb the roundings of
-// the float32 evaluation of both sides.  (Certifying "inside" the same way was tried: the two
-// extra packed operations per pair cost more than the float64 re-evaluations they save.)
+// the float32 evaluation of both sides.
+// INSIDE: pairs are certified "inside" the same way.  From the same error model,
+// |rx| <= (|rx32| + E)(1 + 2.01 eps32), likewise ry, hence D <= k2 (D32 + 1.4143 E), k2 = 1 + 2.01 eps32, and
+// |te| >= T - 1.0001 eps 4.01 eps32 Sz: D < |te| is implied by k2 D32 < T - c' with c' <= c k2, and
+// (T - c')^2 >= T^2 (1 - kappa) - c'^2 (1 / kappa - 1), so D32^2 < T^2 KL - B certifies, KL <= eps^2 (1 - kappa) / k2^2
+// rounded down with a factor (1 - 2^-20) for the float32 roundings; B, made for the other side, is
+// >= 65 c^2 > c'^2 (1 / kappa - 1) (1 + 2^-20) / k2^2.  Where nearly every pose is junk (the basic sampler) the two
+// extra packed operations per pair cost more than the float64 re-evaluations they save -- a group of
+// 64 pairs is re-evaluated when ONE of them is not certified, and junk poses have few such groups;
+// the poses of the co-occurrence sampler have hundreds of inliers, i.e. one in nearly every group:
+// without INSIDE every pair of such a pose is evaluated twice.
 // ------------------------------------------------------------------------------------------
 typedef float v2f __attribute__((ext_vector_type(2)));
 constexpr int SCREEN_KC = 8;         // correspondences per lane and tile (four packed pairs)
@@ -780,7 +789,7 @@ __device__ __forceinline__ void load_posef_uniform(const float *__restrict__ pro
     o.B = p[12];
 }
 
-template <bool MASK>
+template <bool MASK, bool INSIDE = false>
 __device__ __forceinline__ void score_screen_block(const query_dev &q, int nslots, const double *__restrict__ proj,
                                                    const float *__restrict__ projf, const int *__restrict__ nsol,
                                                    int maxsol, double eps, int *__restrict__ counts,
@@ -815,6 +824,12 @@ __device__ __forceinline__ void score_screen_block(const query_dev &q, int nslot
         float KAf = (float)KAd;
         if ((double)KAf < KAd) KAf = __uint_as_float(__float_as_uint(KAf) + 1u);
         const v2f KA = {KAf, KAf};
+        // KL <= eps^2 (1 - kappa) / k2^2, rounded down
+        const double k2 = 1.0 + 2.01 * 5.9604644775390625e-08;
+        const double KLd = eps * eps * (1.0 - 0.015625) / (k2 * k2) * (1.0 - 9.5367431640625e-07);
+        float KLf = (float)KLd;
+        if ((double)KLf > KLd) KLf = __uint_as_float(__float_as_uint(KLf) - 1u);
+        const v2f KL = {KLf, KLf};
         const int tile_sz = SCORE_THREADS * KC;
         for (int base = 0; base < q.n; base += tile_sz) {
             float kx[KC], ky[KC];
@@ -863,12 +878,19 @@ __device__ __forceinline__ void score_screen_block(const query_dev &q, int nslot
                     const v2f pz = pzg[g], rx2 = rx2g[g], hi2 = hi2g[g];
                     unsigned long long n0 = ~__ballot(rx2.x > hi2.x);
                     unsigned long long n1 = ~__ballot(rx2.y > hi2.y);
+                    unsigned long long in0 = 0ull, in1 = 0ull;      // lanes whose pair is inside: certified (INSIDE) or decided in float64
                     if (n0 | n1) {
                         const v2f py = pk_fma(P.p[4], X[g], pk_fma(P.p[5], Y[g], pk_fma(P.p[6], Z[g], ty)));
                         const v2f ry = pk_fma(v[g], pz, -py);
                         const v2f d2 = pk_fma(ry, ry, rx2);
                         n0 = ~__ballot(d2.x > hi2.x);
                         n1 = ~__ballot(d2.y > hi2.y);
+                        if (INSIDE) {
+                            const v2f lo2 = pk_fma(pz * pz, KL, -P.B);
+                            in0 = __ballot(d2.x < lo2.x);
+                            in1 = __ballot(d2.y < lo2.y);
+                            n0 &= ~in0; n1 &= ~in1;
+                        }
                     }
                     if (n0 | n1) {
                         double Pd[12];
@@ -890,11 +912,19 @@ __device__ __forceinline__ void score_screen_block(const query_dev &q, int nslot
                             const double sx = fma(ud, qz, -qx), sy = fma(vd, qz, -qy);
                             const double e2 = fma(sy, sy, sx * sx);
                             const double te = eps * qz;
+                            // the float64 test decides for every lane of the group, the certified ones included
                             const unsigned long long b = __ballot(ok && e2 < te * te);
-                            cnt += __popcll(b);
-                            if (MASK && b) {
-                                const int word = (base + k * SCORE_THREADS + wave * 64) >> 6;
-                                if (lane == 0 && word < words_per_pose) mask[(size_t)slot * words_per_pose + word] = b;
+                            if (h) in1 = b; else in0 = b;
+                        }
+                    }
+                    if (INSIDE || (n0 | n1)) {
+                        cnt += __popcll(in0) + __popcll(in1);
+                        if (MASK) {
+#pragma unroll
+                            for (int h = 0; h < 2; ++h) {
+                                const unsigned long long b = h ? in1 : in0;
+                                const int word = (base + (2 * g + h) * SCORE_THREADS + wave * 64) >> 6;
+                                if (b && lane == 0 && word < words_per_pose) mask[(size_t)slot * words_per_pose + word] = b;
                             }
                         }
                     }

@@ -1580,7 +1580,8 @@ static int batch_run_segmented(pose_amd_batch *b, int sample_mode, uint64_t seed
             for (int i = 0; i < 4; ++i) pose_blocks[i] = std::min(v[i], 1024);
     }
     // matrix-core scoring: most blocks that may share a batch of poses along the correspondences (1: whole-range blocks only)
-    int seg_shares = 8, seg_score_target = 0;
+    int seg_shares = 8, seg_score_target = 0, seg_screen_target = 8;
+    if (const char *e = getenv("POSE_AMD_SEG_SCREEN_TARGET")) seg_screen_target = std::max(1, std::min(1024, atoi(e)));
     if (const char *e = getenv("POSE_AMD_SEG_SCORE_TARGET")) seg_score_target = std::max(0, atoi(e));
     if (const char *e = getenv("POSE_AMD_SEG_SCORE_SHARES")) seg_shares = std::max(1, std::min(16, atoi(e)));
     // (a grid of 16 000 blocks and more measured 5 % slower for the 800-query list: the idle blocks are not free)
@@ -1694,7 +1695,7 @@ static int batch_run_segmented(pose_amd_batch *b, int sample_mode, uint64_t seed
                 } else {
                     // slots per block as in launch_score: as many as possible while the launch keeps about four blocks per compute unit
                     int spb = SCORE_SPB;
-                    while (spb > 8 && (long long)na * cdiv((long long)valid * maxsol, spb) < (ctx->cus ? ctx->cus : 256) * 4) spb >>= 1;
+                    while (spb > 8 && (long long)na * cdiv((long long)valid * maxsol, spb) < (long long)(ctx->cus ? ctx->cus : 256) * seg_screen_target) spb >>= 1;
                     hipLaunchKernelGGL(k_seg_score_screen, dim3(cdiv((long long)valid * maxsol, spb), (unsigned)na), dim3(SCORE_THREADS), 0, stream, L, maxsol,
                                        (const double *)proj, (const float *)projf, (const int *)nsol, prm->eps, counts, spb);
                 }
