@@ -434,6 +434,26 @@ def test_environment_switches_select_paths_with_identical_results(ctx, monkeypat
         assert np.array_equal(a["C"], b["C"]) and np.array_equal(a["Rc"], b["Rc"]) and a["focal"] == b["focal"]
 
 
+def test_advanced_batch_is_scored_the_same_by_both_screens(ctx, monkeypatch):
+    """The co-occurrence sampler's poses go through the packed float32 screen, which certifies pairs
+    outside AND inside the threshold and leaves the rest to float64; POSE_AMD_SEG_SCORE=mfma sends
+    them through the matrix-core screen, whose certificate is a different one.  Both must give the
+    same inlier counts, hence the same kept hypothesis, areas and pose for every query; so must other
+    block sizes of the packed screen."""
+    queries = mixed_queries()
+    kw = dict(seed=21, budget=100, select_mode=SELECT_COVERAGE, early_exit=False)
+    want = ctx.ransac_batch(queries, SAMPLE_ADVANCED, **kw)
+    assert sum(r["inliers"] >= 100 for r in want) >= 5                            # poses with many inliers: the case the inside certificate is for
+    for name, value in (("POSE_AMD_SEG_SCORE", "mfma"), ("POSE_AMD_SEG_SCREEN_TARGET", "64")):
+        monkeypatch.setenv(name, value)
+        got = ctx.ransac_batch(queries, SAMPLE_ADVANCED, **kw)
+        monkeypatch.delenv(name)
+        for a, b in zip(want, got):
+            for k in RESULT_KEYS:
+                assert a[k] == b[k], (name, k)
+            assert np.array_equal(a["C"], b["C"]) and np.array_equal(a["Rc"], b["Rc"]) and a["focal"] == b["focal"]
+
+
 def test_resident_query_list_runs_any_number_of_times(ctx, monkeypatch):
     """pose_amd_batch_create / _run / _destroy: the list is uploaded once and then run with
     different samplers, selections, budgets and seeds; every run returns what pose_amd_ransac_batch
