@@ -248,7 +248,8 @@ __device__ __forceinline__ void score_mfma_core(const query_dev &q, const query_
     __shared__ int s_cnt[POSES];
     __shared__ int s_slot[POSES];
     __shared__ int s_dense[POSES];                          // first correspondence of the pose's float64 scan
-    __shared__ unsigned s_queue[WAVES][MS_QUEUE + 64];      // + one scratch word per lane
+    __shared__ unsigned s_queue[WAVES][MS_QUEUE];
+    __shared__ unsigned s_qn[WAVES];                        // queued pairs of the wave (the wave keeps the same number in a scalar)
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const bool upper = lane >= 32;
     static_assert(POSES == THREADS, "one slot-list entry per thread");
@@ -258,6 +259,7 @@ __device__ __forceinline__ void score_mfma_core(const query_dev &q, const query_
 #pragma unroll
     for (int g = 0; g < MS_GROUPS; ++g) myslot[g] = pl0 + 32 * g < nblk ? vlist[first + pl0 + 32 * g] : 0;
     s_cnt[tid] = 0;
+    if (tid < WAVES) s_qn[tid] = 0u;
     s_dense[tid] = 0x7fffffff;
     s_slot[tid] = tid < nblk ? vlist[first + tid] : -1;
     auto stage = [&](int chunk0, int ct) {
@@ -288,7 +290,7 @@ __device__ __forceinline__ void score_mfma_core(const query_dev &q, const query_
     };
     // screens one 32 x 32 result and queues what it cannot certify
     const unsigned qaddr = (unsigned)(size_t)queue;      // LDS byte address of the wave's queue
-    const unsigned dummy = qaddr + (MS_QUEUE + lane) * 4;   // where lanes without a pair to queue write
+    const unsigned cnt_addr = (unsigned)(size_t)&s_qn[wave];   // LDS byte address of the wave's count of queued pairs
     // A pose with MS_DENSE_ROWS or more uncertified pairs among a lane's 16 of one tile (a pose
     // with many inliers: chance alone leaves about one pair in five hundred open) stops being
     // screened: its operands are zeroed and its constant set to -inf, which certifies every later
@@ -315,14 +317,18 @@ __device__ __forceinline__ void score_mfma_core(const query_dev &q, const query_
                     const int r = 4 * r4 + rr;
                     const unsigned long long m = open[r];
                     if (!m) continue;
-                    // D[i][j]: j = lane % 32, i = 8 (r / 4) + 4 (lane / 32) + r % 4.  Every lane stores;
-                    // the ones without a pair store to a scratch word of their own.
-                    const unsigned pos = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-                    const bool mine = (m >> lane) & 1ull;
-                    mycnt += mine ? 1 : 0;
-                    const unsigned addr = mine ? qaddr + ((unsigned)qn + pos) * 4u : dummy;
-                    *reinterpret_cast<__attribute__((address_space(3))) unsigned *>((uintptr_t)addr) = ent + (unsigned)(8 * r4 + rr);
-                    qn = __builtin_amdgcn_readfirstlane(qn + __popcll(m));
+                    // D[i][j]: j = lane % 32, i = 8 (r / 4) + 4 (lane / 32) + r % 4.  The lanes with an open pair
+                    // (one or two of the 64, as a rule) take a queue position each from the wave's counter in
+                    // LDS and store their entry; the mask of the comparison is their execution mask as it is.
+                    // (Positions from a prefix count over the mask cost eleven vector instructions per
+                    // register with an open pair, a third of this kernel's vector work for junk poses.)
+                    if (__builtin_amdgcn_inverse_ballot_w64(m)) {
+                        unsigned pos;
+                        asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(pos) : "v"(cnt_addr), "v"(1u) : "memory");
+                        *reinterpret_cast<__attribute__((address_space(3))) unsigned *>((uintptr_t)(qaddr + pos * 4u)) = ent + (unsigned)(8 * r4 + rr);
+                        ++mycnt;
+                    }
+                    qn += (int)__popcll(m);
                     if (qn >= 64) {
                         __builtin_amdgcn_wave_barrier();
                         drain(64);
@@ -331,6 +337,8 @@ __device__ __forceinline__ void score_mfma_core(const query_dev &q, const query_
                         __builtin_amdgcn_wave_barrier();
                         if (lane < qn - 64) queue[lane] = keep;
                         qn -= 64;
+                        if (lane == 0) s_qn[wave] = (unsigned)qn;
+                        __builtin_amdgcn_wave_barrier();
                     }
                 }
             }
