@@ -463,15 +463,20 @@ __device__ __forceinline__ void p4pf_finish_block(const query_dev &q, uint32_t h
     // per lane, by whichever lane gets them (it re-derives the normalised problem of the root's
     // hypothesis from the sample, which is cheap next to the rigid fit).
     // The queue shares its memory with the scratch of the root isolation, which is over by then.
+    // Behind the queue every lane has room for the accepted roots of its hypothesis: as a private array
+    // they lived in scratch memory (the sorted insertion indexes them with a loop counter), and the
+    // dependent round trips of that insertion were most of the polish stage's time.
     struct recover_lds { p4pf_root root[128]; unsigned short meta[128]; };      // meta: source lane | root index << 8
-    __shared__ __align__(16) unsigned char s_raw[WAVE_ISO ? (sizeof(p4pf_iso_lds) > sizeof(recover_lds) ? sizeof(p4pf_iso_lds) : sizeof(recover_lds)) : sizeof(recover_lds)];
+    constexpr int ROOT_CAP = 7, ROOT_STRIDE = ROOT_CAP * (int)sizeof(p4pf_root) + 8;   // 58 words apart: the lanes spread over the banks
+    constexpr size_t RECOVER_BYTES = (sizeof(recover_lds) + 15) & ~(size_t)15, FINISH_BYTES = RECOVER_BYTES + 64 * ROOT_STRIDE;
+    __shared__ __align__(16) unsigned char s_raw[WAVE_ISO && sizeof(p4pf_iso_lds) > FINISH_BYTES ? sizeof(p4pf_iso_lds) : FINISH_BYTES];
     p4pf_root *s_root = reinterpret_cast<recover_lds *>(s_raw)->root;
     unsigned short *s_meta = reinterpret_cast<recover_lds *>(s_raw)->meta;
     const int lane = threadIdx.x;
+    p4pf_root *roots = reinterpret_cast<p4pf_root *>(s_raw + RECOVER_BYTES + lane * ROOT_STRIDE);
     const size_t h0 = (size_t)bx * blockDim.x, h = h0 + lane;
     const bool live = h < hyp_count;
     int n = live ? status[h] : -1;
-    p4pf_root roots[10];
     if (WAVE_ISO) {
         double a[50], p[11], q6[7] = {0, 0, 0, 0, 0, 0, 0}, qr6[7] = {0, 0, 0, 0, 0, 0, 0}, lam[12];
         if (n == 0) {
@@ -487,7 +492,7 @@ __device__ __forceinline__ void p4pf_finish_block(const query_dev &q, uint32_t h
         }
         const bool work = n == 0;
         const int nl = p4pf_isolate_wave(*reinterpret_cast<p4pf_iso_lds *>(s_raw), work, q6, qr6, lam);
-        if (work) n = p4pf_polish(a, p, lam, nl, roots);
+        if (work) n = p4pf_polish(a, p, lam, nl, roots, ROOT_CAP);
         __builtin_amdgcn_wave_barrier();
     } else if (n == 0) {
         p4pf_problem pb;
@@ -498,7 +503,9 @@ __device__ __forceinline__ void p4pf_finish_block(const query_dev &q, uint32_t h
 #pragma unroll
         for (int i = 0; i < P4PF_TAIL; ++i) tl[i / 15][i % 15] = Arows[(size_t)i * tail_stride + h];
         n = p4pf_reduce_tail(tl, a);
-        if (n == 0) n = p4pf_roots_sextic(a, pb, roots);
+        double p[11], q6[7], qr6[7], lam[12];
+        if (n == 0) n = p4pf_sextic(a, pb, p, q6, qr6);
+        if (n == 0) n = p4pf_polish(a, p, lam, p4pf_isolate(q6, qr6, lam), roots, ROOT_CAP);
     }
     if (live) nsol[h] = n;
 

@@ -379,7 +379,8 @@ PA_HD int p4pf_isolate(const double (&q)[7], const double (&qr)[7], double (&lam
 
 // Stage 3: Newton polish of every candidate on det P(L), eigenvector, acceptance test.
 // -> accepted roots, ascending zd; the count (0..10), or -1 when an eigenvector component is not finite.
-PA_HD int p4pf_polish(const double (&a)[50], const double (&p)[11], const double (&lam)[12], int nl, p4pf_root roots[10])
+// roots has room for `cap` entries (a sextic has six roots at most; accepted ones beyond cap are dropped).
+PA_HD int p4pf_polish(const double (&a)[50], const double (&p)[11], const double (&lam)[12], int nl, p4pf_root *roots, int cap = 10)
 {
     // derivative of the characteristic polynomial for the Newton polish
     double dp[10];
@@ -388,21 +389,34 @@ PA_HD int p4pf_polish(const double (&a)[50], const double (&p)[11], const double
     int n = 0;
     bool nan = false;
     for (int t = 0; t < nl; ++t) {
-        double L = lam[t];
+        // (no lam[t]: an array indexed by a loop counter lives in scratch memory on the device, a
+        // memory round trip per use)
+        double L = lam[0];
+#pragma unroll
+        for (int k = 1; k < 10; ++k) if (t == k) L = lam[k];
         double S[5][5], y[4];
         // Newton on det P(L).  The eigenvector of the last evaluation is kept once the step is
         // below 1e-13 relative (its error is of the order of that step); a step above 5 % means
         // the start was not in the basin of a root of det P and L is left where it is.
+        // The first step takes det P(L) from the coefficients of the characteristic polynomial: the
+        // candidate is 1e-8 from the root, the step only has to be good to five digits to leave 1e-13,
+        // and the evaluation by elimination that follows judges what it left (a step above 1e-13
+        // there means another one, as before).  It costs a fifteenth of an elimination.
         bool resolve = true;
         for (int it = 0; it < 5; ++it) {
-            p4pf_build_system(a, L, S);
-            const double f = -p4pf_solve_system(S, y);      // = charpoly(L)
+            double f;
+            if (it == 0) {
+                f = poly_eval<10>(p, L);
+            } else {
+                p4pf_build_system(a, L, S);
+                f = -p4pf_solve_system(S, y);               // = charpoly(L)
+            }
             const double df = poly_eval<9>(dp, L);
             const double d = f * p4pf_rcp(df);
             const double scale = fmax(1.0, fabs(L));
-            if (!(d == d) || fabs(d) > 0.05 * scale) { resolve = false; break; }
+            if (!(d == d) || fabs(d) > 0.05 * scale) { resolve = it == 0; break; }
             L -= d;
-            if (fabs(d) <= 1e-13 * scale) { resolve = false; break; }
+            if (it > 0 && fabs(d) <= 1e-13 * scale) { resolve = false; break; }
         }
         if (resolve) {
             p4pf_build_system(a, L, S);
@@ -410,7 +424,7 @@ PA_HD int p4pf_polish(const double (&a)[50], const double (&p)[11], const double
         }
         const double zc = y[0], zb = y[1], w = y[2];
         if (!(zc == zc) || !(zb == zb) || !(w == w)) nan = true;
-        if (w > 0.00001) {
+        if (w > 0.00001 && n < cap) {
             p4pf_root rt;
             rt.f = sqrt(w); rt.zd = L; rt.zc = zc; rt.zb = zb;
             // insertion by ascending zd
