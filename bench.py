@@ -45,7 +45,7 @@ HBM_PEAK_GBS = 8000.0
 SCORE_FLOP_PER_PAIR = 27           # reference formula per (pose, correspondence): 3x4 product, 2 div, distance, compare
 ELIM_FLOP_PER_HYP = 2.28e4         # sparsity-exploiting elimination of the 78x88 template down to the 5x15 tail (22 285) + coefficient formulas
 P3P_FLOP_PER_HYP = 5.0e2           # Kneip P3P + Ferrari quartic per sample
-FINISH_FLOP_PER_HYP = 1.98e4       # executed fp64 lane-operations per hypothesis of the eigen step / pose recovery (counters; no closed-form count)
+FINISH_FLOP_PER_HYP = 1.91e4       # executed fp64 lane-operations per hypothesis of the eigen step / pose recovery (counters; no closed-form count)
 SCREEN_MFMA_FLOP_PER_PAIR = 96     # what the matrix-core screen executes: three v_mfma_f32_32x32x16_bf16 per 32 x 32 pairs
 
 
