@@ -20,9 +20,11 @@ The single-query workload shards the hypothesis range (every rank evaluates its 
 hypotheses of the same query per step, weak scaling) and max-all-reduces the packed
 (inlier count, ~hypothesis id) keys over RCCL; the batch workload gives every rank its own list of
 queries (--scaling weak, the default) or partitions one list over the ranks (--scaling strong), with
-no collective in the data path.
+no collective in the data path.  --gpus 1 --rehearse-collectives runs that path's collectives with one
+rank (the process group over RCCL, the per-step reduction, barriers, gathers of the results).
 
-Prints ONE JSON line on rank 0.
+Prints ONE JSON line on rank 0, and nothing else on standard output: file descriptor 1 is pointed
+at the error stream until that line is due (RCCL prints a banner there when a group is set up).
 """
 import argparse
 import json
@@ -78,6 +80,9 @@ def parse_args(argv=None):
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="dubrovnik with --gpus N: weak = every GPU runs its own list of --queries queries (default); strong = one list of "
                          "--queries queries partitioned over the GPUs")
+    ap.add_argument("--rehearse-collectives", action="store_true",
+                    help="with --gpus 1: initialise the process group all the same and run every collective of the N > 1 path "
+                         "with one rank (on a one-GPU box this is the only way RCCL's part of the path can be run)")
     ap.add_argument("--no-extras", action="store_true",
                     help="default workload only: skip the short passes of the other BASELINE configs that fill config.other_workloads")
     return ap.parse_args(argv)
@@ -110,13 +115,18 @@ def setup_ranks(args):
     ndev = max(1, torch.cuda.device_count())
     dev_index = local_rank % ndev
     red_dev = f"cuda:{dev_index}" if args.backend == "nccl" else "cpu"
-    if world > 1:
+    if world > 1 or args.rehearse_collectives:
         import torch.distributed as dist
         torch.cuda.set_device(dev_index)
+        kw = {}
+        if "RANK" not in os.environ:                 # the one-rank rehearsal outside torch.distributed.run
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29531")
+            kw = dict(rank=0, world_size=1)
         if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index), **kw)
         else:
-            dist.init_process_group("gloo")
+            dist.init_process_group("gloo", **kw)
     return rank, world, dev_index, red_dev, torch, dist
 
 
@@ -139,22 +149,35 @@ class KeyReducer:
     """The one exchange of the hypothesis-sharded path: a max-all-reduce of one packed (count, id)
     key per step, started without waiting and collected before the clock stops, so that it runs
     beside the next step's kernels.  The keys live in a ring of preallocated slots of one device
-    tensor (a slot is filled in place; nothing is allocated inside the timed region)."""
+    tensor (a slot is filled in place; nothing is allocated inside the timed region).  A step's
+    reduction is enqueued by a helper thread (always the same one, so every rank enqueues in step
+    order): filling the slot and handing the collective to RCCL is ~0.1 ms of host time, which would
+    otherwise sit between two steps with the GPU idle -- the library call of the next step releases
+    the interpreter lock while it runs."""
     SLOTS = 8
 
     def __init__(self, torch, dist, device):
         self.dist = dist
         self.buf = torch.zeros(self.SLOTS, dtype=torch.int64, device=device) if dist is not None else None
         self.views = [self.buf[i:i + 1] for i in range(self.SLOTS)] if dist is not None else []
-        self.work = [None] * self.SLOTS
+        self.pending = [None] * self.SLOTS                   # futures of the enqueueing thread; their results are the collectives' handles
         self.n = 0
         self.keys = []
+        self.pool = None
+        if dist is not None:
+            from concurrent.futures import ThreadPoolExecutor
+            on_gpu = str(device).startswith("cuda")
+            self.pool = ThreadPoolExecutor(1, initializer=(lambda: torch.cuda.set_device(device)) if on_gpu else None)
+
+    def _enqueue(self, slot, key):
+        self.views[slot].fill_(key)
+        return self.dist.all_reduce(self.views[slot], op=self.dist.ReduceOp.MAX, async_op=True)
 
     def _finish(self, slot):
-        if self.work[slot] is not None:
-            self.work[slot].wait()
+        if self.pending[slot] is not None:
+            self.pending[slot].result().wait()
             self.keys.append(int(self.views[slot].item()))
-            self.work[slot] = None
+            self.pending[slot] = None
 
     def begin(self, key):
         if self.dist is None:
@@ -163,8 +186,7 @@ class KeyReducer:
         slot = self.n % self.SLOTS
         self.n += 1
         self._finish(slot)                                   # the reduction that used this slot SLOTS steps ago
-        self.views[slot].fill_(int(key))
-        self.work[slot] = self.dist.all_reduce(self.views[slot], op=self.dist.ReduceOp.MAX, async_op=True)
+        self.pending[slot] = self.pool.submit(self._enqueue, slot, int(key))
 
     def collect(self):
         """Waits for every reduction still in flight; -> the reduced keys in step order."""
@@ -174,11 +196,21 @@ class KeyReducer:
         out, self.keys = self.keys, []
         return out
 
+    def close(self):
+        if self.pool is not None:
+            self.pool.shutdown(wait=True)
+            self.pool = None
+
 
 def main():
     args = parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return self_launch(args)
+    # Libraries write to file descriptor 1 behind Python's back (RCCL prints a version banner there when
+    # a process group is initialised): until the one JSON line is due, descriptor 1 is the error stream.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     env = setup_ranks(args)
     rank, world, dist = env[0], env[1], env[5]
     if args.workload == "dubrovnik":
@@ -191,9 +223,13 @@ def main():
             extras = other_workloads(args, env)
             if rank == 0:
                 out["config"]["other_workloads"] = extras
+    sys.stdout.flush()
+    os.dup2(real_stdout, 1)
+    os.close(real_stdout)
     if rank == 0:
-        print(json.dumps(out))
-    if world > 1:
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        os.dup2(2, 1)                                # whatever the shutdown prints is no part of the line either
         dist.destroy_process_group()
     return 0
 
@@ -240,13 +276,13 @@ def bench_single(args, env):
     q = synth.make_query(args.matches, args.inlier_frac, seed=2, known_focal=args.known_focal)
     ctx.set_query(q["kx"], q["ky"], q["X"], q["Y"], q["Z"], q["width"], q["height"], q["focal"])
     H = args.hyps
-    red = KeyReducer(torch, dist if world > 1 else None, red_dev)
+    red = KeyReducer(torch, dist, red_dev)
 
     def step(i):
         # hypothesis ids are global: rank r owns [ (i*world + r) * H, +H )
         ctx.sample(SAMPLE_BASIC, 1002, 0, ((i * world + rank) * H) % (1 << 31), H, export=False)
         r = ctx.ransac_run(SELECT_INLIERS, 0.5, early_exit=False)
-        if world > 1:
+        if dist is not None:
             gh = ((i * world + rank) * H + r["best_hyp"]) & shard.KEY_ID_MASK
             red.begin(shard.pack_key(r["inliers"], gh))
         return r
@@ -254,7 +290,7 @@ def bench_single(args, env):
     def sync():
         ctx.synchronize()
         torch.cuda.synchronize()
-        if world > 1:
+        if dist is not None:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -271,10 +307,10 @@ def bench_single(args, env):
         poses += last["poses_scored"]
         for k, v in ctx.last_timing().items():
             tim[k] = tim.get(k, 0.0) + v
-    global_best = [shard.unpack_key(k) for k in red.collect()] if world > 1 else []   # every step's reduction has completed inside the timed region
+    global_best = [shard.unpack_key(k) for k in red.collect()] if dist is not None else []   # every step's reduction has completed inside the timed region
     sync()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -311,6 +347,8 @@ def bench_single(args, env):
             out["config"]["pcie_inclusive_hypotheses_per_s"] = round(2 * H / (time.perf_counter() - t1), 1)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_single(ctx, q, args)
+    red.collect()
+    red.close()
     ctx.close()
     return out
 
@@ -533,7 +571,7 @@ def bench_dubrovnik(args, env):
         for c in ctxs:
             c.synchronize()
         torch.cuda.synchronize()
-        if world > 1:
+        if dist is not None:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -548,7 +586,7 @@ def bench_dubrovnik(args, env):
         dt = time.perf_counter() - t0
     if batched:
         res = convert(res)
-    if world > 1:
+    if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -643,7 +681,7 @@ def bench_knn(args, env):
     def sync():
         ctx.synchronize()
         torch.cuda.synchronize()
-        if world > 1:
+        if dist is not None:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -658,7 +696,7 @@ def bench_knn(args, env):
             ms[k] = ms.get(k, 0.0) + v
     sync()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())

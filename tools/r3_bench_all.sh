@@ -17,4 +17,7 @@ run knn --workload knn --steps 5 --warmup 1 || exit 1
 run gloo2_single --gpus 2 --backend gloo --steps 5 --warmup 1 --no-cpu-baseline || exit 1
 run gloo2_dub_weak --gpus 2 --backend gloo --workload dubrovnik --early-exit --steps 3 --warmup 1 --no-cpu-baseline || exit 1
 run gloo2_dub_strong --gpus 2 --backend gloo --workload dubrovnik --early-exit --scaling strong --steps 3 --warmup 1 --no-cpu-baseline || exit 1
+# the collectives of the N > 1 path with one rank: the only way RCCL's part can run on a one-GPU box
+run rccl1_single --gpus 1 --rehearse-collectives --steps 20 --warmup 3 --no-cpu-baseline || exit 1
+run rccl1_dub --gpus 1 --rehearse-collectives --workload dubrovnik --early-exit --steps 5 --warmup 2 --no-cpu-baseline || exit 1
 tools/r3_sweep.sh "$OUT/sweep" || exit 1

@@ -25,7 +25,7 @@ for name in ("dub_exit", "dub_adv", "dub_fixed", "p3p", "large", "knn"):
     lines = [l for l in open(log) if l.startswith("{")] if os.path.exists(log) else []
     if lines:
         open(os.path.join(out, "r3_%s_under_rocprof.json" % name), "w").write(lines[-1])
-for name in ("bench", "bench100", "p3p", "large", "dub_fixed", "dub_exit", "dub_adv", "dub_exit_host_queries", "knn", "gloo2_single", "gloo2_dub_weak",
+for name in ("bench", "bench100", "p3p", "large", "dub_fixed", "dub_exit", "dub_adv", "dub_exit_host_queries", "knn", "rccl1_single", "rccl1_dub", "gloo2_single", "gloo2_dub_weak",
              "gloo2_dub_strong"):
     f = os.path.join(bench, name + ".json")
     lines = [l for l in open(f) if l.startswith("{")] if os.path.exists(f) else []
