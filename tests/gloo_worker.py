@@ -31,6 +31,18 @@ def main():
     # the same reduction started without waiting, several in flight (what bench.py does per step)
     handles = [shard.reduce_best_begin(key + i, dist) for i in range(3)]
     best_async = [shard.reduce_best_end(h) for h in handles]
+    # bench.py's reducer: a ring of eight preallocated slots, every step's reduction enqueued by a helper
+    # thread; eleven steps reuse slots, and the keys come back in step order
+    import torch
+    import bench
+    red = bench.KeyReducer(torch, dist, "cpu")
+    for i in range(11):
+        red.begin(1000 * i + rank)
+    reduced = red.collect()
+    red.begin(7 + rank)
+    reduced += red.collect()
+    red.close()
+    reducer_ok = reduced == [1000 * i + world - 1 for i in range(11)] + [7 + world - 1]
     # by-query partition: every query is owned by exactly one rank
     costs = [4000 + 37 * i % 2000 for i in range(50)]
     mine = shard.query_shard(costs, rank, world)
@@ -45,7 +57,7 @@ def main():
         with open(out_path, "w") as f:
             json.dump({"world": world, "count": count, "hyp": hyp, "ref_count": int(ref["hyposet"]), "ref_hyp": int(ref["best_step"]),
                        "queries_ok": flat == list(range(50)), "loads": loads,
-                       "async_ok": best_async == [best + i for i in range(3)]}, f)
+                       "async_ok": best_async == [best + i for i in range(3)], "reducer_ok": reducer_ok}, f)
     dist.barrier()
     dist.destroy_process_group()
 

@@ -40,5 +40,5 @@ def test_two_ranks_agree_with_sequential_loop(tmp_path):
     r = json.loads(out.read_text())
     assert r["world"] == 2
     assert (r["count"], r["hyp"]) == (r["ref_count"], r["ref_hyp"]) and r["count"] > 0
-    assert r["queries_ok"] and r["async_ok"]
+    assert r["queries_ok"] and r["async_ok"] and r["reducer_ok"]
     assert abs(r["loads"][0] - r["loads"][1]) <= 0.02 * sum(r["loads"])
