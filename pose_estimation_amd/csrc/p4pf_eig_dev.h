@@ -72,6 +72,9 @@ PA_HD void poly_eval2(const double (&c)[N + 1], double x, double &v, double &dv)
 // Iteration budget and relative tolerance of the bracketed root refinement.  Critical points
 // of the derivative chain only delimit brackets and the sextic's roots are polished afterwards
 // on det P(L), so neither needs full precision.
+#ifndef P4PF_POLISH_FIRST_STEP_FROM_COEFFICIENTS
+#define P4PF_POLISH_FIRST_STEP_FROM_COEFFICIENTS 1
+#endif
 #ifndef P4PF_REFINE_ITS
 #define P4PF_REFINE_ITS 60
 #endif
@@ -405,7 +408,7 @@ PA_HD int p4pf_polish(const double (&a)[50], const double (&p)[11], const double
         bool resolve = true;
         for (int it = 0; it < 5; ++it) {
             double f;
-            if (it == 0) {
+            if (P4PF_POLISH_FIRST_STEP_FROM_COEFFICIENTS && it == 0) {
                 f = poly_eval<10>(p, L);
             } else {
                 p4pf_build_system(a, L, S);
@@ -414,9 +417,9 @@ PA_HD int p4pf_polish(const double (&a)[50], const double (&p)[11], const double
             const double df = poly_eval<9>(dp, L);
             const double d = f * p4pf_rcp(df);
             const double scale = fmax(1.0, fabs(L));
-            if (!(d == d) || fabs(d) > 0.05 * scale) { resolve = it == 0; break; }
+            if (!(d == d) || fabs(d) > 0.05 * scale) { resolve = P4PF_POLISH_FIRST_STEP_FROM_COEFFICIENTS && it == 0; break; }
             L -= d;
-            if (it > 0 && fabs(d) <= 1e-13 * scale) { resolve = false; break; }
+            if ((!P4PF_POLISH_FIRST_STEP_FROM_COEFFICIENTS || it > 0) && fabs(d) <= 1e-13 * scale) { resolve = false; break; }
         }
         if (resolve) {
             p4pf_build_system(a, L, S);
