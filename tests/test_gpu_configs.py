@@ -552,3 +552,22 @@ def test_two_rank_rehearsal_runs_the_hip_path_on_every_rank():
     assert r.returncode == 0, r.stderr.decode()[-2000:]
     line = json.loads(r.stdout.decode().strip().splitlines()[-1])
     assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["value"] > 0 and line["config"]["best_inliers"] >= 12
+
+
+def test_one_rank_rehearsal_of_the_rccl_collectives_prints_one_json_line():
+    """bench.py --gpus 1 --rehearse-collectives: the process group over RCCL with one rank, the per-step
+    max-all-reduce from the slot ring (enqueued by the helper thread), barriers and the reduction of the
+    times -- what a one-GPU box can run of the N > 1 path.  Standard output holds the JSON line and
+    nothing else: RCCL prints a version banner on file descriptor 1 when the group is set up, which
+    bench.py keeps away from it."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--rehearse-collectives", "--steps", "3", "--warmup", "1",
+                        "--hyps", "65536", "--no-cpu-baseline"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=280)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    out = r.stdout.decode().strip().splitlines()
+    assert len(out) == 1, out[:3]
+    line = json.loads(out[0])
+    assert line["n_gpus"] == 1 and line["value"] > 0 and line["config"]["best_inliers"] >= 12
+    assert line["config"]["global_best_inliers_last_step"] == line["config"]["best_inliers"]      # one rank: the reduced key is its own
